@@ -1,0 +1,202 @@
+"""Generate tests/golden/*.npz -- run ONLY in the build container (needs /root/reference).
+
+TEST INFRASTRUCTURE ONLY.  What it pins:
+  g1  reference ResNet1D_SE(1,2) + best_ptbxl.pth, eval, hash inputs   (reference class, imported)
+  g2  same net, train mode (dropout p=0), CE loss, fwd+bwd             (reference class, imported)
+  g3  reference 12-lead ResNet1D_SE + reference FocalLoss, 3 Adam+OneCycleLR steps (imported)
+  g4  reference FocalLoss known answers                                 (imported)
+  g5  oracle ECGMultimodalModel (restatement), B=8: eval/train outputs, grads, 3-step Adam losses
+  g6  oracle ResNet18 (restatement of torchvision's): per-stage statistics
+and, before writing g1-g3, that oracle.ref_models.ResNet1D_SE is BIT-IDENTICAL to the reference
+class on the same weights/inputs (it is the same sequence of torch ops).
+
+The reference's source never leaves /root/reference: only tensors (inputs by formula, expected
+outputs, and a tensor copy of best_ptbxl.pth's 79 entries) are written.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import fill, ref_models as O  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    sys.path.insert(0, REF)
+    import train_signal_only as R1          # reference ResNet1D_SE (1-lead script)
+    import train_signal_12_af as R12        # reference ResNet1D_SE + FocalLoss (12-lead script)
+
+    # ---------------- g1 / g2: best_ptbxl.pth through the reference class --------------------
+    sd = torch.load(os.path.join(REF, "best_ptbxl.pth"), map_location="cpu", weights_only=True)
+    np.savez_compressed(os.path.join(OUT, "best_ptbxl_tensors.npz"), **{k: npy(v) for k, v in sd.items()})
+    ref = R1.ResNet1D_SE(input_channels=1, num_classes=2)
+    ref.load_state_dict(sd, strict=True)
+    mine = O.ResNet1D_SE(1, 2)
+    mine.load_state_dict(sd, strict=True)
+    g1 = {}
+    for L in (2476, 5000):
+        x = fill.hash_tensor((4, 1, L), 77 + L, 1.5)
+        ref.eval(); mine.eval()
+        with torch.no_grad():
+            yr = ref(x)
+            ym = mine(x)
+            st = mine.stages(x)
+        assert torch.equal(yr, ym), "oracle ResNet1D_SE is not bit-identical to the reference class"
+        g1[f"logits_{L}"] = npy(yr)
+        for i, s in enumerate(st):
+            g1[f"stage{i}_mean_{L}"] = npy(s.mean(dim=(0, 2)))
+            g1[f"stage{i}_absmean_{L}"] = npy(s.abs().mean(dim=(0, 2)))
+        g1[f"pooled_{L}"] = npy(st[-1].mean(dim=2))
+    np.savez_compressed(os.path.join(OUT, "g1_ptbxl_eval.npz"), **g1)
+
+    g2 = {}
+    for net in (ref, mine):
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    x = fill.hash_tensor((4, 1, 2476), 91, 1.5)
+    y = torch.tensor([0, 1, 1, 0])
+    outs = []
+    for net in (ref, mine):
+        net.zero_grad()
+        lo = net(x)
+        loss = F.cross_entropy(lo, y)
+        loss.backward()
+        outs.append((lo.detach(), loss.detach(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                     {k: v.clone() for k, v in net.state_dict().items() if "running" in k}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    g2["logits"], g2["loss"] = npy(outs[0][0]), npy(outs[0][1])
+    for k, v in outs[0][2].items():
+        g2["grad." + k] = npy(v)
+    for k, v in outs[0][3].items():
+        g2["buf." + k] = npy(v)
+    np.savez_compressed(os.path.join(OUT, "g2_ptbxl_train.npz"), **g2)
+
+    # ---------------- g3: 12-lead, reference FocalLoss, Adam + OneCycleLR ---------------------
+    ref12 = R12.ResNet1D_SE(input_channels=12)
+    mine12 = O.ResNet1D_SE(12, 2)
+    fill.hash_fill_module(ref12, "sig12.")
+    fill.hash_fill_module(mine12, "sig12.")
+    x12 = fill.hash_tensor((8, 12, 5000), 555, 1.5)
+    y12 = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    traj = []
+    for net, crit in ((ref12, R12.FocalLoss(alpha=1.0, gamma=2.0)), (mine12, O.FocalLoss(1.0, 2.0))):
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, steps_per_epoch=4, epochs=30)
+        losses, lrs, b1s = [], [], []
+        for _ in range(3):
+            lrs.append(opt.param_groups[0]["lr"]); b1s.append(opt.param_groups[0]["betas"][0])
+            opt.zero_grad()
+            loss = crit(net(x12), y12)
+            loss.backward()
+            opt.step(); sch.step()
+            losses.append(loss.item())
+        net.eval()
+        with torch.no_grad():
+            fin = net(x12)
+        traj.append((losses, fin, lrs, b1s))
+    assert traj[0][0] == traj[1][0] and torch.equal(traj[0][1], traj[1][1])
+    np.savez_compressed(os.path.join(OUT, "g3_sig12_steps.npz"), losses=np.array(traj[0][0]),
+                        final_logits=npy(traj[0][1]), lrs=np.array(traj[0][2]), beta1s=np.array(traj[0][3]))
+
+    # ---------------- g4: FocalLoss known answers ---------------------------------------------
+    lg = torch.tensor([[2.0, -1.0], [0.3, 0.1]]); tg = torch.tensor([0, 1])
+    v_ref = R12.FocalLoss()(lg, tg)
+    assert abs(v_ref.item() - 0.12070029228925705) < 1e-9            # SURVEY 8c known answer
+    lg2 = fill.hash_tensor((16, 2), 4242, 3.0); tg2 = torch.from_numpy((fill.hash_uniform(16, 4243) > 0).astype(np.int64))
+    v2 = R12.FocalLoss(alpha=0.25, gamma=2.0)(lg2, tg2)
+    v2u = R12.FocalLoss(reduce=False)(lg2, tg2)
+    assert torch.equal(v2, O.FocalLoss(0.25, 2.0)(lg2, tg2))
+    np.savez_compressed(os.path.join(OUT, "g4_focal.npz"), kat=npy(v_ref), logits=npy(lg2), targets=npy(tg2),
+                        loss_a025=npy(v2), loss_unreduced=npy(v2u))
+
+    # ---------------- g5: full multimodal oracle (restatement) --------------------------------
+    g5 = {}
+    img, sig, clin, lab = fill.synthetic_batch(8, salt=5)
+    model = O.disable_dropout(fill.hash_fill_module(O.ECGMultimodalModel(2, 16), "mm."))
+    model.eval()
+    with torch.no_grad():
+        out = model(img, sig, clin)
+    for n, o in zip(("img_logits", "sig_logits", "clin_logits", "fusion_logits", "var_loss", "soft_w"), out):
+        g5["eval." + n] = npy(o)
+    model.train()
+    model.zero_grad()
+    out = model(img, sig, clin)
+    loss = O.multimodal_loss(out, lab)
+    loss.backward()
+    for n, o in zip(("img_logits", "sig_logits", "clin_logits", "fusion_logits", "var_loss", "soft_w"), out):
+        g5["train." + n] = npy(o)
+    g5["train.loss"] = npy(loss)
+    for k, p in model.named_parameters():
+        g5["gnorm." + k] = np.array(0.0 if p.grad is None else p.grad.norm().item())
+    for k in ("image_encoder.conv1.weight", "image_encoder.layer4.1.conv2.weight", "image_encoder.fc.weight"):
+        g5["gslice." + k] = npy(dict(model.named_parameters())[k].grad.flatten()[:512])
+    for k in ("fusion_classifier.0.weight", "attention_fusion.weights", "signal_encoder.layer3.se.fc.0.weight",
+              "clinical_encoder.0.weight", "signal_encoder.initial.0.weight"):
+        g5["grad." + k] = npy(dict(model.named_parameters())[k].grad)
+    for frozen in (False, True):
+        m = O.disable_dropout(fill.hash_fill_module(O.ECGMultimodalModel(2, 16), "mm."))
+        if frozen:
+            O.freeze_encoders(m)
+        m.train()
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        ls = []
+        for _ in range(3):
+            opt.zero_grad()
+            l = O.multimodal_loss(m(img, sig, clin), lab)
+            l.backward(); opt.step(); ls.append(l.item())
+        g5["adam3.frozen" if frozen else "adam3.unfrozen"] = np.array(ls)
+    np.savez_compressed(os.path.join(OUT, "g5_multimodal.npz"), **g5)
+
+    # ---------------- g6: ResNet18 restatement, per-stage statistics --------------------------
+    g6 = {}
+    r18 = fill.hash_fill_module(O.ResNet18(num_classes=256), "r18.")
+    assert sum(p.numel() for p in r18.parameters()) == 11307840
+    assert len(O.ResNet18().state_dict()) == 122
+    for tag, shape in (("224", (2, 3, 224, 224)), ("250x2500", (1, 3, 250, 2500))):
+        x = fill.hash_tensor(shape, 606)
+        r18.eval()
+        with torch.no_grad():
+            st = r18.stages(x)
+            g6[f"feat_{tag}"] = npy(r18(x))
+        for i, s in enumerate(st):
+            g6[f"shape{i}_{tag}"] = np.array(s.shape)
+            g6[f"stage{i}_mean_{tag}"] = npy(s.mean(dim=(0, 2, 3)))
+    r18.train()
+    x = fill.hash_tensor((4, 3, 64, 64), 607)
+    f = r18(x)
+    f.square().mean().backward()
+    g6["train_feat_64"] = npy(f)
+    g6["train_gnorm_conv1_64"] = np.array(r18.conv1.weight.grad.norm().item())
+    g6["train_gnorm_l4_64"] = np.array(r18.layer4[1].conv2.weight.grad.norm().item())
+    g6["train_bn1_rm_64"] = npy(r18.bn1.running_mean)
+    np.savez_compressed(os.path.join(OUT, "g6_resnet18.npz"), **g6)
+    print("goldens written to", OUT)
+    for f_ in sorted(os.listdir(OUT)):
+        print(f"  {f_}: {os.path.getsize(os.path.join(OUT, f_)) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
