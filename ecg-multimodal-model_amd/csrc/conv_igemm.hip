@@ -1,0 +1,318 @@
+// Implicit-GEMM convolution on MFMA for channels-last (NHWC / NLC) activations, gfx950.
+//
+//   forward : dst[n,oh,ow,co] = sum_{r,s,ci} src[n, oh*st-p+r, ow*st-p+s, ci] * W[co][r][s][ci]
+//   dgrad   : dst[n,h,w,ci]   = sum_{r,s,co} src[n,(h+p-r)/st,(w+p-s)/st,co] * W'[ci][r][s][co]
+//
+// GEMM view: pixels (n,h,w) are the MFMA *column* index and channels the *row* index, i.e. the packed
+// weights are the A operand and the gathered activation rows the B operand.  With that orientation
+// each lane of a 16x16 accumulator owns 4 consecutive channels of one pixel, so the epilogue stores
+// 8 B (bf16) / 16 B (f32) per lane into the channels-last output and the BatchNorm partial sums are
+// a 16-lane butterfly.
+//
+// Tile: 128 pixels x BN channels x 128 bytes of K per stage (64 bf16 / 32 f32 channels of one tap),
+// 256 threads = 4 waves (2 pixel halves x 2 channel halves), double-buffered LDS with register
+// staging (issue the next stage's global loads before the MFMAs, write them to LDS after).
+// LDS rows are 128 B with a 16-B-chunk XOR swizzle (chunk ^= row & 7) so the ds_read_b128 fragment
+// reads of 16 consecutive rows spread over the 64 banks.
+// dtype: bf16 -> v_mfma_f32_16x16x32_bf16; f32 -> 4 x v_mfma_f32_16x16x4_f32 per 16-B fragment pair
+// (exact fp32 fma chain -- the 1e-3 parity path).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                  acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc, 0, 0, 0);
+  }
+};
+
+struct IgemmParams {
+  const void* src;
+  const void* wpk;
+  void* dst;
+  const float* bias;
+  const void* addend;
+  float* stats;  // [2*gridDim.x][2][Cd] partial (sum, sumsq) or null
+  int Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad_h, pad_w;
+  int M;  // destination pixels
+  int act;
+};
+
+constexpr int BM = 128;       // pixels per workgroup
+constexpr int ROWB = 128;     // bytes of K per LDS row per stage
+constexpr int NTHREADS = 256;
+
+template <typename T, int BN, int MODE, int ST>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KBE = ROWB / (int)sizeof(T);  // channels per stage
+  constexpr int TP = 4;                       // 16-pixel tiles per wave (64 pixels)
+  constexpr int TC = BN / 32;                 // 16-channel tiles per wave
+  constexpr int NWV = BN / 32;                // weight vectors per thread per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // layout: [2 stages][ (BN + BM) rows ][128 B]
+  constexpr int STAGE_BYTES = (BN + BM) * ROWB;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wp = wave & 1, wc = wave >> 1;  // pixel half, channel half
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const T* __restrict__ src = (const T*)p.src;
+  const T* __restrict__ wpk = (const T*)p.wpk;
+
+  // ---- per-thread gather bookkeeping: 4 activation rows + NWV weight rows, one 16-B chunk each
+  const int chunk = tid & 7, lrow = tid >> 3;  // lrow 0..31
+  int nb[4], hb[4], wb[4];
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int pix = m0 + lrow + 32 * i;
+    rok[i] = pix < p.M;
+    int pp = rok[i] ? pix : 0;
+    int n = pp / (p.Hd * p.Wd);
+    int rem = pp - n * (p.Hd * p.Wd);
+    int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+    nb[i] = n * p.Hs;
+    if (MODE == 0) {
+      hb[i] = hd * p.stride - p.pad_h;
+      wb[i] = wd * p.stride - p.pad_w;
+    } else {
+      hb[i] = hd + p.pad_h;
+      wb[i] = wd + p.pad_w;
+    }
+  }
+  const int RS = p.R * p.S;
+  const int cpt = (p.Cs + KBE - 1) / KBE;  // stages per tap
+  const int nk = RS * cpt;
+
+  u32x4 va[4], vw[NWV];
+  auto gload = [&](int it) {
+    int tap = it / cpt, cc = it - tap * cpt;
+    int r = tap / p.S, s = tap - r * p.S;
+    int ch = cc * KBE + chunk * VEC;
+    bool chok = ch < p.Cs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int hs, ws;
+      bool ok = rok[i] && chok;
+      if (MODE == 0) {
+        hs = hb[i] + r;
+        ws = wb[i] + s;
+      } else {
+        int th = hb[i] - r, tw = wb[i] - s;
+        ok = ok && th >= 0 && tw >= 0;
+        if (ST == 2) {
+          ok = ok && ((th | tw) & 1) == 0;
+          hs = th >> 1;
+          ws = tw >> 1;
+        } else {
+          hs = th;
+          ws = tw;
+        }
+      }
+      ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        size_t off = ((size_t)(nb[i] + hs) * p.Ws + ws) * p.Cs + ch;
+        v = *reinterpret_cast<const u32x4*>(src + off);
+      }
+      va[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      int j = n0 + lrow + 32 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (j < p.Cd && chok) {
+        size_t off = ((size_t)j * RS + tap) * p.Cs + ch;
+        v = *reinterpret_cast<const u32x4*>(wpk + off);
+      }
+      vw[i] = v;
+    }
+  };
+  const int pch = (chunk ^ (lrow & 7)) << 4;  // swizzled 16-B chunk offset (row & 7 == lrow & 7)
+  auto lstore = [&](int stage) {
+    unsigned char* sW = smem + stage * STAGE_BYTES;
+    unsigned char* sX = sW + BN * ROWB;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) *reinterpret_cast<u32x4*>(sW + (lrow + 32 * i) * ROWB + pch) = vw[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sX + (lrow + 32 * i) * ROWB + pch) = va[i];
+  };
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int stage) {
+    const unsigned char* sW = smem + stage * STAGE_BYTES;
+    const unsigned char* sX = sW + BN * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[TC], fb[TP];
+      const int lch = ks * 4 + fq;
+#pragma unroll
+      for (int a = 0; a < TC; ++a) {
+        int row = wc * (BN / 2) + a * 16 + fr;
+        fa[a] = *reinterpret_cast<const u32x4*>(sW + row * ROWB + ((lch ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        int row = wp * 64 + b * 16 + fr;
+        fb[b] = *reinterpret_cast<const u32x4*>(sX + row * ROWB + ((lch ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const bool more = it + 1 < nk;
+    if (more) gload(it + 1);
+    compute(it & 1);
+    if (more) lstore((it + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel (fr) x 4 consecutive channels (fq*4 + j) of each 16x16 tile
+  T* __restrict__ dst = (T*)p.dst;
+  const T* __restrict__ addend = (const T*)p.addend;
+  const bool vec_ok = (p.Cd & 3) == 0;
+#pragma unroll
+  for (int a = 0; a < TC; ++a) {
+    const int ch0 = n0 + wc * (BN / 2) + a * 16 + fq * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ch0 + j < p.Cd) bv[j] = p.bias[ch0 + j];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int pix = m0 + wp * 64 + b * 16 + fr;
+      const bool pok = pix < p.M;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] + bv[j];
+      if (addend && pok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ch0 + j < p.Cd) v[j] += Elem<T>::ld(addend + (size_t)pix * p.Cd + ch0 + j);
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (pok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s1[j] += v[j];
+          s2[j] += v[j] * v[j];
+        }
+        T* o = dst + (size_t)pix * p.Cd + ch0;
+        if (vec_ok && ch0 + 3 < p.Cd) {
+          if (sizeof(T) == 2) {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(o) = pk;
+          } else {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (ch0 + j < p.Cd) Elem<T>::st(o + j, v[j]);
+        }
+      }
+    }
+    if (p.stats) {
+      // butterfly over the 16 pixel lanes, then lane fr==0 of each quad writes 4 channels
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          s1[j] += __shfl_xor(s1[j], o, 64);
+          s2[j] += __shfl_xor(s2[j], o, 64);
+        }
+      }
+      if (fr == 0) {
+        float* row = p.stats + (size_t)(blockIdx.x * 2 + wp) * 2 * p.Cd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ch0 + j < p.Cd) {
+            row[ch0 + j] = s1[j];
+            row[p.Cd + ch0 + j] = s2[j];
+          }
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int MODE, int ST>
+int launch_one(const IgemmParams& p, hipStream_t stream) {
+  dim3 grid(ceil_div(p.M, BM), ceil_div(p.Cd, BN));
+  size_t lds = 2 * (size_t)(BN + BM) * ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BN, MODE, ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_kernel<T, BN, MODE, ST>), grid, dim3(NTHREADS), lds, stream, p);
+  ECG_CHECK_LAUNCH("igemm_kernel");
+  return 0;
+}
+
+template <typename T>
+int launch_T(const IgemmParams& p, int mode, hipStream_t stream) {
+  const bool wide = p.Cd > 64;
+  if (mode == 0) return wide ? launch_one<T, 128, 0, 1>(p, stream) : launch_one<T, 64, 0, 1>(p, stream);
+  if (p.stride == 1) return wide ? launch_one<T, 128, 1, 1>(p, stream) : launch_one<T, 64, 1, 1>(p, stream);
+  if (p.stride == 2) return wide ? launch_one<T, 128, 1, 2>(p, stream) : launch_one<T, 64, 1, 2>(p, stream);
+  ECG_FAIL(ECGMM_ERR_SHAPE, "conv dgrad: stride %d unsupported (1 or 2)", p.stride);
+}
+
+}  // namespace
+
+// rows of the BatchNorm partial-sum buffer a forward launch writes (2 per 128-pixel tile)
+int ecg_conv_stats_rows(long M) { return 2 * ceil_div(M, BM); }
+
+// mode 0: forward (src = x, dst = y); mode 1: dgrad (src = dy, dst = dx; g still describes the FORWARD conv)
+int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst,
+                   const float* bias, const void* addend, float* stats, int act, hipStream_t stream) {
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.src = src; p.wpk = wpk; p.dst = dst; p.bias = bias; p.addend = addend; p.stats = stats; p.act = act;
+  p.R = g.R; p.S = g.S; p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+  if (mode == 0) {
+    p.Hs = g.H; p.Ws = g.W; p.Cs = g.Cin; p.Hd = g.OH; p.Wd = g.OW; p.Cd = g.Cout;
+  } else {
+    p.Hs = g.OH; p.Ws = g.OW; p.Cs = g.Cout; p.Hd = g.H; p.Wd = g.W; p.Cd = g.Cin;
+  }
+  long M = (long)g.N * p.Hd * p.Wd;
+  if (M <= 0 || M > 0x7fffffffL) ECG_FAIL(ECGMM_ERR_SHAPE, "conv: pixel count %ld out of range", M);
+  p.M = (int)M;
+  const int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  if (p.Cs % vec != 0) ECG_FAIL(ECGMM_ERR_SHAPE, "conv: reduction channels %d not a multiple of %d", p.Cs, vec);
+  if (dtype == ECGMM_BF16) return launch_T<bf16_t>(p, mode, stream);
+  if (dtype == ECGMM_F32) return launch_T<float>(p, mode, stream);
+  ECG_FAIL(ECGMM_ERR_DTYPE, "conv: bad dtype %d", dtype);
+}

@@ -1,0 +1,460 @@
+// Stem convolutions (few input channels, 7-wide filter, stride 2) on MFMA, gfx950:
+//   2-D: Conv2d(3,64,7,2,3) over the NCHW fp32 image  (torchvision resnet18.conv1)
+//   1-D: Conv1d(cin,64,7,2,3) over the NCL fp32 signal (ResNet1D_SE.initial[0]; R = 1)
+// The input is consumed in its native NCHW layout: a workgroup stages the (TH*2+R-2) x (TW*2+6)
+// input patch of every channel into LDS with W-contiguous (coalesced) global reads, and the MFMA
+// operand fragments are gathered straight from that patch -- the filter taps are regrouped as
+// K = (c, r) groups x 8 (7 s-taps + one zero-weight pad), so a lane's 8-deep k-slice is 8 consecutive
+// floats of one patch row.  Output is channels-last [N, OH, OW, 64] in the compute dtype.
+// Forward: A = packed weights (rows = out channels), B = patch (cols = pixels).
+// Wgrad:   A = dy^T via transposing LDS reads, B = patch values of 8 consecutive pixels (stride 2).
+#include "common.h"
+
+__device__ __host__ inline size_t align_up_dev(size_t a) { return (a + 15) & ~(size_t)15; }
+
+namespace {
+
+constexpr int STEM_CO = 64;
+constexpr int MAXG = 24;  // (c, r) groups supported (2-D: 21, 1-D 12-lead: 12)
+
+struct StemParams {
+  const float* x;    // [N, Cin, H, W] fp32
+  const void* wpk;   // fwd: [64][KP] T, k = G*8 + s (zero for s == 7 and padded groups)
+  void* y;           // fwd out / wgrad dy: [N, OH, OW, 64] T
+  const float* bias;
+  float* stats;      // fwd: [4*grid][2][64]
+  float* slab;       // wgrad: [split][64][NG*8]
+  int N, Cin, H, W, OH, OW, R, pad_h;
+  int TH, TW;        // output tile (TH*TW == 128)
+  int tiles_h, tiles_w;
+  int NG;            // Cin * R
+  int tiles_per_split;
+};
+
+template <typename T> struct StemCfg;
+template <> struct StemCfg<bf16_t> { static constexpr int WPAD = 8; };   // row stride (KP + 8) bf16: 16-B reads conflict-free
+template <> struct StemCfg<float> { static constexpr int WPAD = 1; };
+
+__device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patch, int n, int oh0, int ow0, int PH,
+                                                int PW, int PWS) {
+  const int total = p.Cin * PH * PWS;
+  const float* xin = p.x + (size_t)n * p.Cin * p.H * p.W;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    int pw = i % PWS;
+    int t = i / PWS;
+    int ph = t % PH, c = t / PH;
+    int ih = oh0 * 2 - p.pad_h + ph, iw = ow0 * 2 - 3 + pw;
+    float v = 0.f;
+    if (pw < PW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+      v = xin[((size_t)c * p.H + ih) * p.W + iw];
+    patch[i] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ksteps = (p.NG + 3) / 4;
+  const int KP = ksteps * 32;
+  const int WS = KP + StemCfg<T>::WPAD;  // weight row stride (elements)
+  const int PH = (p.TH - 1) * 2 + p.R, PW = (p.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+  T* sW = reinterpret_cast<T*>(smem);
+  float* patch = reinterpret_cast<float*>(smem + align_up_dev((size_t)STEM_CO * WS * sizeof(T)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  int bid = blockIdx.x;
+  const int tw_i = bid % p.tiles_w;
+  bid /= p.tiles_w;
+  const int th_i = bid % p.tiles_h;
+  const int n = bid / p.tiles_h;
+  const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+
+  // stage weights (K-contiguous rows) and the input patch
+  const T* wg = (const T*)p.wpk;
+  for (int i = tid; i < STEM_CO * KP; i += 256) {
+    int co = i / KP, k = i - co * KP;
+    sW[co * WS + k] = wg[i];
+  }
+  stem_load_patch(p, patch, n, oh0, ow0, PH, PW, PWS);
+  __syncthreads();
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int segs = p.TW / 16;
+  int prow[2], pcol[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int t = wave * 2 + b;  // 16-pixel tile index within the workgroup (8 tiles)
+    prow[b] = t / segs;
+    pcol[b] = (t % segs) * 16 + fr;
+  }
+
+  for (int ks = 0; ks < ksteps; ++ks) {
+    int G = ks * 4 + fq;
+    if (G >= p.NG) G = p.NG - 1;  // padded groups carry zero weights; keep the read in bounds
+    const int c = G / p.R, r = G - c * p.R;
+    float bv[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float* src = patch + (c * PH + prow[b] * 2 + r) * PWS + pcol[b] * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float2 v = *reinterpret_cast<const float2*>(src + 2 * j);
+        bv[b][2 * j] = v.x;
+        bv[b][2 * j + 1] = v.y;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      u32x4 fb[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = pack16<bf16_t>(bv[b]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        u32x4 fa = *reinterpret_cast<const u32x4*>(sW + (a * 16 + fr) * WS + ks * 32 + fq * 8);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                              __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+      }
+    } else {
+      // f32: the k index of a 16x16x4 step is the lane quad; walk the 4 groups x 8 taps of this kstep
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int G2 = ks * 4 + g;
+        if (G2 >= p.NG) G2 = p.NG - 1;
+        const int c2 = G2 / p.R, r2 = G2 - c2 * p.R;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int s = hf * 4 + fq;
+          float fbv[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) fbv[b] = patch[(c2 * PH + prow[b] * 2 + r2) * PWS + pcol[b] * 2 + s];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            float fav = sW[(a * 16 + fr) * WS + (ks * 4 + g) * 8 + s];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fav, fbv[b], acc[a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: lane = pixel fr of tile b, channels a*16 + fq*4 + j
+  T* y = (T*)p.y;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int ch0 = a * 16 + fq * 4;
+    float bvv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bvv[j] = p.bias[ch0 + j];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oh = oh0 + prow[b], ow = ow0 + pcol[b];
+      if (oh < p.OH && ow < p.OW) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[a][b][j] + bvv[j];
+          s1[j] += v[j];
+          s2[j] += v[j] * v[j];
+        }
+        T* o = y + (((size_t)n * p.OH + oh) * p.OW + ow) * STEM_CO + ch0;
+        if (sizeof(T) == 2) {
+          uint2 pk;
+          pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(o) = pk;
+        } else {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          s1[j] += __shfl_xor(s1[j], o, 64);
+          s2[j] += __shfl_xor(s2[j], o, 64);
+        }
+      }
+      if (fr == 0) {
+        float* row = p.stats + (size_t)(blockIdx.x * 4 + wave) * 2 * STEM_CO;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          row[ch0 + j] = s1[j];
+          row[STEM_CO + ch0 + j] = s2[j];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: slab[split][co][kidx] = sum over this split's tiles of dy[pix][co] * patch(pix, kidx)
+// wave w owns k-tiles {w, w+4, w+8} (16 kidx each) x all 4 co-tiles.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int DYS = sizeof(T) == 2 ? 144 : 320;  // dy row stride in bytes (64 ch + pad)
+  const int PH = (p.TH - 1) * 2 + p.R, PW = (p.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+  unsigned char* sDY = smem;                                  // [128 pix][DYS]
+  float* patch = reinterpret_cast<float*>(smem + 128 * DYS);  // [Cin][PH][PWS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int NK = p.NG * 8;
+  const int ktiles = (NK + 15) / 16;
+  const int segs = p.TW / 16;
+  const int total_tiles = p.N * p.tiles_h * p.tiles_w;
+  const int t_begin = blockIdx.x * p.tiles_per_split;
+  const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this lane's B column = kidx of each owned k-tile -> (c, r, s)
+  int kc[3], krr[3], ksx[3];
+  bool kok[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    int kidx = (wave + 4 * b) * 16 + fr;
+    kok[b] = (wave + 4 * b) < ktiles && kidx < NK;
+    int kk = kok[b] ? kidx : 0;
+    int G = kk >> 3;
+    ksx[b] = kk & 7;
+    kc[b] = G / p.R;
+    krr[b] = G - kc[b] * p.R;
+  }
+
+  const T* dy = (const T*)p.y;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int bid = tile;
+    const int tw_i = bid % p.tiles_w;
+    bid /= p.tiles_w;
+    const int th_i = bid % p.tiles_h;
+    const int n = bid / p.tiles_h;
+    const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+    __syncthreads();  // previous tile's LDS fully consumed
+    // dy tile: pixel index within tile = trow*TW + tcol ; 16 B per thread-vector
+    constexpr int CH = 64 * (int)sizeof(T) / 16;
+    for (int i = tid; i < 128 * CH; i += 256) {
+      int pix = i / CH, chunk = i % CH;
+      int trow = pix / p.TW, tcol = pix % p.TW;
+      int oh = oh0 + trow, ow = ow0 + tcol;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (oh < p.OH && ow < p.OW)
+        v = *reinterpret_cast<const u32x4*>(dy + (((size_t)n * p.OH + oh) * p.OW + ow) * STEM_CO +
+                                            chunk * (16 / (int)sizeof(T)));
+      *reinterpret_cast<u32x4*>(sDY + pix * DYS + chunk * 16) = v;
+    }
+    stem_load_patch(p, patch, n, oh0, ow0, PH, PW, PWS);
+    __syncthreads();
+
+    if constexpr (sizeof(T) == 2) {
+      const int q = fr >> 2, pq = fr & 3;
+      for (int st = 0; st < 4; ++st) {  // 32 pixels per step = two 16-pixel segments
+        // A: dy^T, k rows = pixels st*32 + 8*fq .. +7
+        u32x4 fa[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const unsigned char* a0 = sDY + (st * 32 + 8 * fq + q) * DYS + (a * 16 + 4 * pq) * 2;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0)));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0 + 4 * DYS)));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fa[a] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+        }
+        // B: 8 consecutive pixels (st*32 + 8*fq + j) of one kidx
+        const int pix0 = st * 32 + 8 * fq;
+        const int trow = pix0 / p.TW, tcol0 = pix0 % p.TW;  // 8 | 16 | TW: the 8 pixels share a row
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          float bv[8];
+          const float* src = patch + (kc[b] * PH + trow * 2 + krr[b]) * PWS + tcol0 * 2 + ksx[b];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bv[j] = kok[b] ? src[2 * j] : 0.f;
+          u32x4 fb = pack16<bf16_t>(bv);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                                __builtin_bit_cast(bf16x8_t, fb), acc[a][b], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int st = 0; st < 32; ++st) {  // 4 pixels per step
+        const int pix = st * 4 + fq;
+        const int trow = pix / p.TW, tcol = pix % p.TW;
+        float fa[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const float*>(sDY + pix * DYS + (a * 16 + fr) * 4);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          float fb = kok[b] ? patch[(kc[b] * PH + trow * 2 + krr[b]) * PWS + tcol * 2 + ksx[b]] : 0.f;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb, acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // D[row = co = a*16 + fq*4 + j][col = kidx]
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    int kidx = (wave + 4 * b) * 16 + fr;
+    if ((wave + 4 * b) >= ktiles || kidx >= NK) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        p.slab[((size_t)blockIdx.x * STEM_CO + a * 16 + fq * 4 + j) * NK + kidx] = acc[a][b][j];
+  }
+}
+
+// grad[co][c][r][s] = sum_split slab[split][co][(c*R + r)*8 + s]   (s < 7)
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int NG,
+                                         int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = STEM_CO * NG * 7;
+  if (i >= total) return;
+  int s = i % 7;
+  int t = i / 7;
+  int G = t % NG, co = t / NG;
+  const int NK = NG * 8;
+  float acc = 0.f;
+  for (int k = 0; k < nsplit; ++k) acc += slab[((size_t)k * STEM_CO + co) * NK + G * 8 + s];
+  grad[i] = accumulate ? grad[i] + acc : acc;
+}
+
+// OIHW fp32 [64][Cin][R][7] -> [64][KP] T with k = (c*R + r)*8 + s
+template <typename T>
+__global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int NG, int KP) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= STEM_CO * KP) return;
+  int co = i / KP, k = i - co * KP;
+  int G = k >> 3, s = k & 7;
+  float v = (G < NG && s < 7) ? w[((size_t)co * NG + G) * 7 + s] : 0.f;
+  Elem<T>::st(out + i, v);
+}
+
+struct StemShape {
+  int OH, OW, TH, TW, tiles_h, tiles_w, NG, KP;
+};
+int stem_shape(int Cin, int H, int W, int R, StemShape& s) {
+  if (R != 1 && R != 7) ECG_FAIL(ECGMM_ERR_SHAPE, "stem: R=%d (1 or 7)", R);
+  s.NG = Cin * R;
+  if (s.NG > MAXG) ECG_FAIL(ECGMM_ERR_SHAPE, "stem: Cin*R=%d > %d", s.NG, MAXG);
+  int pad_h = R / 2;
+  s.OH = (H + 2 * pad_h - R) / 2 + 1;
+  s.OW = (W + 6 - 7) / 2 + 1;
+  if (R == 1) { s.TH = 1; s.TW = 128; }
+  else { s.TH = 8; s.TW = 16; }
+  s.tiles_h = ceil_div(s.OH, s.TH);
+  s.tiles_w = ceil_div(s.OW, s.TW);
+  s.KP = ((s.NG + 3) / 4) * 32;
+  return 0;
+}
+void fill_params(StemParams& p, const StemShape& s, int N, int Cin, int H, int W, int R) {
+  memset(&p, 0, sizeof(p));
+  p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.OH = s.OH; p.OW = s.OW; p.R = R; p.pad_h = R / 2;
+  p.TH = s.TH; p.TW = s.TW; p.tiles_h = s.tiles_h; p.tiles_w = s.tiles_w; p.NG = s.NG;
+}
+size_t patch_bytes(const StemShape& s, int Cin, int R) {
+  int PH = (s.TH - 1) * 2 + R, PW = (s.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+  return (size_t)Cin * PH * PWS * sizeof(float);
+}
+
+}  // namespace
+
+size_t ecg_stem_packed_elems(int Cin, int R) { return (size_t)STEM_CO * (((Cin * R + 3) / 4) * 32); }
+int ecg_stem_stats_rows(int N, int Cin, int H, int W, int R) {
+  StemShape s;
+  if (stem_shape(Cin, H, W, R, s)) return -1;
+  return 4 * N * s.tiles_h * s.tiles_w;
+}
+
+int ecg_stem_pack(int dtype, const float* w, void* out, int Cin, int R, hipStream_t stream) {
+  int NG = Cin * R, KP = ((NG + 3) / 4) * 32;
+  int n = STEM_CO * KP;
+  if (dtype == ECGMM_BF16)
+    hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(ceil_div(n, 256)), dim3(256), 0, stream, w, (bf16_t*)out, NG, KP);
+  else
+    hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(ceil_div(n, 256)), dim3(256), 0, stream, w, (float*)out, NG, KP);
+  ECG_CHECK_LAUNCH("stem_pack");
+  return 0;
+}
+
+int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
+                 int H, int W, int R, hipStream_t stream) {
+  StemShape s;
+  ECG_TRY(stem_shape(Cin, H, W, R, s));
+  StemParams p;
+  fill_params(p, s, N, Cin, H, W, R);
+  p.x = x; p.wpk = wpk; p.y = y; p.bias = bias; p.stats = stats;
+  const size_t esz = dtype_size(dtype);
+  const int WS = s.KP + (dtype == ECGMM_BF16 ? 8 : 1);
+  size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + patch_bytes(s, Cin, R);
+  dim3 grid(N * s.tiles_h * s.tiles_w);
+  if (dtype == ECGMM_BF16) {
+    hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+  } else if (dtype == ECGMM_F32) {
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void*)stem_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      once = true;
+    }
+    hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, stream, p);
+  } else {
+    ECG_FAIL(ECGMM_ERR_DTYPE, "stem: bad dtype %d", dtype);
+  }
+  ECG_CHECK_LAUNCH("stem_fwd");
+  return 0;
+}
+
+static int stem_nsplit(int total_tiles) { return total_tiles < 1024 ? total_tiles : 1024; }
+
+size_t ecg_stem_wgrad_workspace(int N, int Cin, int H, int W, int R) {
+  StemShape s;
+  if (stem_shape(Cin, H, W, R, s)) return 0;
+  return (size_t)stem_nsplit(N * s.tiles_h * s.tiles_w) * STEM_CO * s.NG * 8 * sizeof(float);
+}
+
+int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int accumulate, void* workspace,
+                   size_t workspace_bytes, int N, int Cin, int H, int W, int R, hipStream_t stream) {
+  StemShape s;
+  ECG_TRY(stem_shape(Cin, H, W, R, s));
+  const int total = N * s.tiles_h * s.tiles_w;
+  const int nsplit = stem_nsplit(total);
+  size_t need = (size_t)nsplit * STEM_CO * s.NG * 8 * sizeof(float);
+  if (!workspace || workspace_bytes < need)
+    ECG_FAIL(ECGMM_ERR_WORKSPACE, "stem wgrad: workspace %zu < %zu", workspace_bytes, need);
+  StemParams p;
+  fill_params(p, s, N, Cin, H, W, R);
+  p.x = x; p.y = const_cast<void*>(dy); p.slab = (float*)workspace;
+  p.tiles_per_split = ceil_div(total, nsplit);
+  const int grid = ceil_div(total, p.tiles_per_split);
+  size_t lds = 128 * (size_t)(dtype == ECGMM_BF16 ? 144 : 320) + patch_bytes(s, Cin, R);
+  if (dtype == ECGMM_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, p);
+  else if (dtype == ECGMM_F32) hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(256), lds, stream, p);
+  else ECG_FAIL(ECGMM_ERR_DTYPE, "stem wgrad: bad dtype %d", dtype);
+  ECG_CHECK_LAUNCH("stem_wgrad");
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_CO * s.NG * 7, 256)), dim3(256), 0, stream,
+                     (const float*)workspace, grad, grid, s.NG, accumulate);
+  ECG_CHECK_LAUNCH("stem_wgrad_reduce");
+  return 0;
+}

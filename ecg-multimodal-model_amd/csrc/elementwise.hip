@@ -1,0 +1,762 @@
+// HBM-bound passes over channels-last activations [M pixels][C channels] (gfx950):
+// BatchNorm finalize / apply (+ReLU, +residual, +SE gate), BatchNorm backward (reduce + apply),
+// 3x3/s2 max-pool (fused with BN+ReLU) and its backward, global average pool, layout packs.
+// All tensor traffic is 16 B per lane; each thread keeps a FIXED channel chunk (so per-channel
+// coefficients live in registers) and walks rows.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize: partial (sum, sumsq) rows -> mean / invstd / affine coefficients / running stats
+// coef layout: [4][C] = scale, shift, mean, invstd
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean,
+                                                           float* running_var, long long* nbt, float momentum,
+                                                           float eps, float* __restrict__ coef) {
+  __shared__ double sh[2][16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;  // 16 row slices
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int r = slice; r < rows; r += 16) {
+      const float* row = partial + (size_t)r * 2 * C;
+      s1 += (double)row[c];
+      s2 += (double)row[C + c];
+    }
+  }
+  sh[0][slice][threadIdx.x & 63] = s1;
+  sh[1][slice][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) {
+      s1 += sh[0][k][threadIdx.x];
+      s2 += sh[1][k][threadIdx.x];
+    }
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float sc = g * invstd;
+    coef[c] = sc;
+    coef[C + c] = b - (float)mean * sc;
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = invstd;
+    if (running_mean) {
+      double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// eval mode: coefficients straight from the running statistics
+__global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                    float eps, float* coef) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.f / sqrtf(rv[c] + eps);
+  float sc = (gamma ? gamma[c] : 1.f) * invstd;
+  coef[c] = sc;
+  coef[C + c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+  coef[2 * C + c] = rm[c];
+  coef[3 * C + c] = invstd;
+}
+
+// column partial sums of a [M][C] tensor (producer was not a conv epilogue), same row format
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void col_stats_kernel(const T* __restrict__ x, long M, int C,
+                                                               float* __restrict__ partial) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float sh[EW_THREADS][2 * VEC + 1];
+  const int cpr = C / VEC, rpi = EW_THREADS / cpr;
+  const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+  for (long r = (long)blockIdx.x * rpi + r0; r < M; r += (long)gridDim.x * rpi) {
+    float f[VEC];
+    unpack16<T>(ld16(x + r * C + chunk * VEC), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      s1[j] += f[j];
+      s2[j] += f[j] * f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sh[threadIdx.x][j] = s1[j];
+    sh[threadIdx.x][VEC + j] = s2[j];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += EW_THREADS) {
+    int which = o / C, c = o % C;
+    int ck = c / VEC, j = c % VEC;
+    float s = 0.f;
+    for (int k = 0; k < rpi; ++k) s += sh[k * cpr + ck][which * VEC + j];
+    partial[(size_t)blockIdx.x * 2 * C + o] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN apply: out = relu?( (y*scale+shift) * gate[n][c] + residual ), residual optionally affine
+// ------------------------------------------------------------------------------------------------
+struct BnActParams {
+  const void* y;
+  const float* coef;       // [4][C]
+  const void* res;         // nullable
+  const float* rcoef;      // nullable: residual = res*rscale + rshift
+  const float* gate;       // nullable [N][C]
+  void* out;
+  long M;
+  int C, rows_per_sample, relu;
+};
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_act_kernel(BnActParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpr = p.C / VEC, rpi = EW_THREADS / cpr;
+  const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
+  const int c0 = chunk * VEC;
+  float sc[VEC], sh[VEC], rs[VEC], rb[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = p.coef[c0 + j];
+    sh[j] = p.coef[p.C + c0 + j];
+    rs[j] = p.rcoef ? p.rcoef[c0 + j] : 1.f;
+    rb[j] = p.rcoef ? p.rcoef[p.C + c0 + j] : 0.f;
+  }
+  const T* y = (const T*)p.y;
+  const T* res = (const T*)p.res;
+  T* out = (T*)p.out;
+  for (long r = (long)blockIdx.x * rpi + r0; r < p.M; r += (long)gridDim.x * rpi) {
+    float f[VEC], g[VEC];
+    unpack16<T>(ld16(y + r * p.C + c0), f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = f[j] * sc[j] + sh[j];
+    if (p.gate) {
+      const float* gp = p.gate + (r / p.rows_per_sample) * p.C + c0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] *= gp[j];
+    }
+    if (res) {
+      unpack16<T>(ld16(res + r * p.C + c0), g);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] += g[j] * rs[j] + rb[j];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    st16(out + r * p.C + c0, pack16<T>(f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN backward.  dz = [maskref > 0] * dout * gate[n][c] + addc[n][c]   (each factor optional)
+//   reduce : partial rows of (sum dz, sum dz*xhat), xhat = (y - mean) * invstd
+//   finalize: dgamma, dbeta, bcoef = [3][C] (gamma*invstd, mean_dz, mean_dz_xhat)
+//   apply  : dy = c1 * (dz - c2 - xhat * c3); optional dz store; optional partial sum of dy (conv bias grad)
+// ------------------------------------------------------------------------------------------------
+struct BnBwdParams {
+  const void* dout;
+  const void* maskref;   // nullable
+  const float* gate;     // nullable [N][C]
+  const float* addc;     // nullable [N][C]
+  const void* y;         // raw conv output the BN normalised
+  const float* coef;     // forward coef [4][C] (mean at 2C, invstd at 3C)
+  const float* bcoef;    // [3][C] (apply only)
+  void* dy;              // apply only
+  void* dz_out;          // nullable (apply only)
+  float* partial;        // reduce: [grid][2][C]; apply: nullable [grid][C] partial sum(dy)
+  long M;
+  int C, rows_per_sample;
+};
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_kernel(BnBwdParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float shm[EW_THREADS][2 * VEC + 1];
+  const int cpr = p.C / VEC, rpi = EW_THREADS / cpr;
+  const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
+  const int c0 = chunk * VEC;
+  float mean[VEC], inv[VEC], k1[VEC], k2[VEC], k3[VEC], a1[VEC], a2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mean[j] = p.coef[2 * p.C + c0 + j];
+    inv[j] = p.coef[3 * p.C + c0 + j];
+    a1[j] = a2[j] = 0.f;
+    if (APPLY) {
+      k1[j] = p.bcoef[c0 + j];
+      k2[j] = p.bcoef[p.C + c0 + j];
+      k3[j] = p.bcoef[2 * p.C + c0 + j];
+    }
+  }
+  const T* dout = (const T*)p.dout;
+  const T* mref = (const T*)p.maskref;
+  const T* y = (const T*)p.y;
+  for (long r = (long)blockIdx.x * rpi + r0; r < p.M; r += (long)gridDim.x * rpi) {
+    float d[VEC], m[VEC], v[VEC];
+    unpack16<T>(ld16(dout + r * p.C + c0), d);
+    unpack16<T>(ld16(y + r * p.C + c0), v);
+    if (mref) {
+      unpack16<T>(ld16(mref + r * p.C + c0), m);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[j] = m[j] > 0.f ? d[j] : 0.f;
+    }
+    // dz_out carries the masked gradient only (the residual-branch gradient), before gate / addc
+    if (APPLY && p.dz_out) st16((T*)p.dz_out + r * p.C + c0, pack16<T>(d));
+    if (p.gate) {
+      const float* gp = p.gate + (r / p.rows_per_sample) * p.C + c0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[j] *= gp[j];
+    }
+    if (p.addc) {
+      const float* ap = p.addc + (r / p.rows_per_sample) * p.C + c0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[j] += ap[j];
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float xh = (v[j] - mean[j]) * inv[j];
+        a1[j] += d[j];
+        a2[j] += d[j] * xh;
+      }
+    } else {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float xh = (v[j] - mean[j]) * inv[j];
+        o[j] = k1[j] * (d[j] - k2[j] - xh * k3[j]);
+      }
+      u32x4 pk = pack16<T>(o);
+      st16((T*)p.dy + r * p.C + c0, pk);
+      if (p.partial) {
+        float back[VEC];
+        unpack16<T>(pk, back);  // sum what was actually stored
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a1[j] += back[j];
+      }
+    }
+  }
+  if (!APPLY || p.partial) {
+    constexpr int NQ = APPLY ? 1 : 2;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      shm[threadIdx.x][j] = a1[j];
+      if (!APPLY) shm[threadIdx.x][VEC + j] = a2[j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < NQ * p.C; o += EW_THREADS) {
+      int which = o / p.C, c = o % p.C;
+      int ck = c / VEC, j = c % VEC;
+      float s = 0.f;
+      for (int k = 0; k < rpi; ++k) s += shm[k * cpr + ck][which * VEC + j];
+      p.partial[(size_t)blockIdx.x * NQ * p.C + o] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+                                                               double count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ coef, float* dgamma,
+                                                               float* dbeta, float* __restrict__ bcoef) {
+  __shared__ double sh[2][16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = slice; r < rows; r += 16) {
+      const float* row = partial + (size_t)r * 2 * C;
+      s1 += (double)row[c];
+      s2 += (double)row[C + c];
+    }
+  sh[0][slice][threadIdx.x & 63] = s1;
+  sh[1][slice][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) {
+      s1 += sh[0][k][threadIdx.x];
+      s2 += sh[1][k][threadIdx.x];
+    }
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    bcoef[c] = (gamma ? gamma[c] : 1.f) * coef[3 * C + c];
+    bcoef[C + c] = (float)(s1 / count);
+    bcoef[2 * C + c] = (float)(s2 / count);
+  }
+}
+
+// sum rows of a [rows][C] fp32 partial buffer -> out[C] (conv bias grads, linear bias grads)
+__global__ void rows_sum_kernel(const float* __restrict__ partial, int rows, int C, float* out, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 2 / pad 1 max-pool fused with BN apply + ReLU (stem of both encoders; H may be 1)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bnrelu_maxpool_kernel(const T* __restrict__ y,
+                                                                    const float* __restrict__ coef, T* __restrict__ out,
+                                                                    unsigned char* __restrict__ idx, int N, int H,
+                                                                    int W, int C, int OH, int OW) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpr = C / VEC;
+  long total = (long)N * OH * OW * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int chunk = (int)(i % cpr);
+    long pix = i / cpr;
+    int ow = (int)(pix % OW);
+    long t = pix / OW;
+    int oh = (int)(t % OH), n = (int)(t / OH);
+    int c0 = chunk * VEC;
+    float best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      int h = oh * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int w = ow * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float f[VEC];
+        unpack16<T>(ld16(y + (((size_t)n * H + h) * W + w) * C + c0), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float a = fmaxf(f[j] * coef[c0 + j] + coef[C + c0 + j], 0.f);
+          // value as it would be stored (so ties are decided on the stored precision)
+          if (sizeof(T) == 2) a = bf2f(f2bf(a));
+          if (a > best[j]) {
+            best[j] = a;
+            bi[j] = kh * 3 + kw;
+          }
+        }
+      }
+    }
+    st16(out + pix * C + c0, pack16<T>(best));
+    unsigned char* ip = idx + pix * C + c0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ip[j] = (unsigned char)bi[j];
+  }
+}
+
+// dz[n,h,w,c] = sum over the <=4 windows containing (h,w): dp[win] * [idx[win]==tap] * [p[win] > 0]
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void maxpool_relu_bwd_kernel(const T* __restrict__ dp,
+                                                                      const T* __restrict__ pooled,
+                                                                      const unsigned char* __restrict__ idx,
+                                                                      T* __restrict__ dz, int N, int H, int W, int C,
+                                                                      int OH, int OW) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpr = C / VEC;
+  long total = (long)N * H * W * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int chunk = (int)(i % cpr);
+    long pix = i / cpr;
+    int w = (int)(pix % W);
+    long t = pix / W;
+    int h = (int)(t % H), n = (int)(t / H);
+    int c0 = chunk * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;  // windows with oh*2-1 <= h <= oh*2+1
+    int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      if (oh >= OH) continue;
+      int kh = h - (oh * 2 - 1);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        if (ow >= OW) continue;
+        int kw = w - (ow * 2 - 1);
+        int tap = kh * 3 + kw;
+        size_t o = (((size_t)n * OH + oh) * OW + ow) * C + c0;
+        float d[VEC], pv[VEC];
+        unpack16<T>(ld16(dp + o), d);
+        unpack16<T>(ld16(pooled + o), pv);
+        const unsigned char* ip = idx + o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (ip[j] == tap && pv[j] > 0.f) acc[j] += d[j];
+      }
+    }
+    st16(dz + pix * C + c0, pack16<T>(acc));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// global average pool over the rows of each sample: [N][R][C] T -> [N][C] f32; and its broadcast
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, int R,
+                                                             int C, const float* __restrict__ coef) {
+  // one block per (sample, 64-channel group); 4 row slices x 64 channels
+  __shared__ float sh[4][64];
+  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int r = slice; r < R; r += 4) s += Elem<T>::ld(x + ((size_t)n * R + r) * C + c);
+  sh[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    float m = s / (float)R;
+    if (coef) m = m * coef[c] + coef[C + c];  // mean of an affine map = affine map of the mean
+    out[(size_t)n * C + c] = m;
+  }
+}
+
+template <typename T>
+__global__ void bcast_rows_kernel(const float* __restrict__ v, T* __restrict__ out, long total, int R, int C,
+                                  float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long n = i / ((long)R * C);
+    Elem<T>::st(out + i, v[n * C + c] * scale);
+  }
+}
+
+// per-sample row reduction of dpre*z for the SE gate gradient:
+// dg[n][c] = sum_r [maskref>0] * dout[n,r,c] * (y[n,r,c]*scale[c] + shift[c])
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void se_gate_grad_kernel(const T* __restrict__ dout,
+                                                                  const T* __restrict__ maskref,
+                                                                  const T* __restrict__ y,
+                                                                  const float* __restrict__ coef,
+                                                                  float* __restrict__ dg, int R, int C) {
+  __shared__ float sh[4][64];
+  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C) {
+    float sc = coef[c], sf = coef[C + c];
+    for (int r = slice; r < R; r += 4) {
+      size_t o = ((size_t)n * R + r) * C + c;
+      float d = Elem<T>::ld(dout + o);
+      if (Elem<T>::ld(maskref + o) > 0.f) s += d * (Elem<T>::ld(y + o) * sc + sf);
+    }
+  }
+  sh[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice == 0 && c < C)
+    dg[(size_t)n * C + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout / packing
+// ------------------------------------------------------------------------------------------------
+// OIHW f32 -> fwd pack [Cout][RS][Cin] T and dgrad pack [Cin][RS][Cout] T
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgr, int Cout,
+                                   int Cin, int RS) {
+  long total = (long)Cout * Cin * RS;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int tap = (int)(i % RS);
+    long r = i / RS;
+    int ci = (int)(r % Cin), co = (int)(r / Cin);
+    float v = w[i];
+    if (fwd) Elem<T>::st(fwd + ((size_t)co * RS + tap) * Cin + ci, v);
+    if (dgr) Elem<T>::st(dgr + ((size_t)ci * RS + tap) * Cout + co, v);
+  }
+}
+
+// NCHW f32 <-> NHWC T through a 32x32 LDS transpose (coalesced both ways)
+template <typename T, bool TO_NHWC>
+__global__ __launch_bounds__(256) void nchw_nhwc_kernel(const void* __restrict__ src_, void* __restrict__ dst_, int C,
+                                                        long HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (TO_NHWC) {
+    const float* src = (const float*)src_ + (size_t)n * C * HW;
+    T* dst = (T*)dst_ + (size_t)n * C * HW;
+    for (int k = ty; k < 32; k += 8) {
+      int c = c0 + k;
+      long pp = p0 + tx;
+      tile[k][tx] = (c < C && pp < HW) ? src[(size_t)c * HW + pp] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      long pp = p0 + k;
+      int c = c0 + tx;
+      if (c < C && pp < HW) Elem<T>::st(dst + (size_t)pp * C + c, tile[tx][k]);
+    }
+  } else {
+    const T* src = (const T*)src_ + (size_t)n * C * HW;
+    float* dst = (float*)dst_ + (size_t)n * C * HW;
+    for (int k = ty; k < 32; k += 8) {
+      long pp = p0 + k;
+      int c = c0 + tx;
+      tile[k][tx] = (c < C && pp < HW) ? Elem<T>::ld(src + (size_t)pp * C + c) : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      int c = c0 + k;
+      long pp = p0 + tx;
+      if (c < C && pp < HW) dst[(size_t)c * HW + pp] = tile[tx][k];
+    }
+  }
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Elem<T>::st(dst + i, src[i]);
+}
+template <typename T>
+__global__ void uncast_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = Elem<T>::ld(src + i);
+}
+
+inline int ew_grid(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+inline bool chunk_ok(int C, int dtype) {
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  if (C % vec) return false;
+  int cpr = C / vec;
+  return cpr <= EW_THREADS && (EW_THREADS % cpr) == 0;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, what)                 \
+  if ((dtype) == ECGMM_BF16) { CALL_BF16; }                          \
+  else if ((dtype) == ECGMM_F32) { CALL_F32; }                       \
+  else ECG_FAIL(ECGMM_ERR_DTYPE, what ": bad dtype %d", (int)(dtype))
+
+int ecg_bn_rows(int dtype, long M, int C) {
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  int rpi = EW_THREADS / (C / vec);
+  return ew_grid(M, rpi * 8);
+}
+
+int ecg_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                    float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, count, gamma,
+                     beta, rm, rv, nbt, momentum, eps, coef);
+  ECG_CHECK_LAUNCH("bn_finalize");
+  return 0;
+}
+
+int ecg_bn_eval_coef(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                     float* coef, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, C, gamma, beta, rm, rv, eps,
+                     coef);
+  ECG_CHECK_LAUNCH("bn_eval_coef");
+  return 0;
+}
+
+int ecg_col_stats(int dtype, const void* x, long M, int C, float* partial, int* rows_out, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "col_stats: C=%d unsupported", C);
+  int grid = ecg_bn_rows(dtype, M, C);
+  *rows_out = grid;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(col_stats_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, M,
+                                C, partial),
+             hipLaunchKernelGGL(col_stats_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, stream, (const float*)x, M, C,
+                                partial),
+             "col_stats");
+  ECG_CHECK_LAUNCH("col_stats");
+  return 0;
+}
+
+int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
+               int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act: C=%d unsupported", C);
+  BnActParams p;
+  p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
+  p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  int grid = ew_grid(M, (EW_THREADS / (C / vec)) * 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, stream, p),
+             hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_act");
+  ECG_CHECK_LAUNCH("bn_act");
+  return 0;
+}
+
+// full BN backward: reduce -> finalize -> apply.  scratch: partial rows [rows][2][C] + bcoef [3][C]
+size_t ecg_bn_bwd_scratch(int dtype, long M, int C) {
+  return ((size_t)ecg_bn_rows(dtype, M, C) * 2 * C + 3 * C) * sizeof(float);
+}
+
+int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
+               int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma, float* dbeta,
+               void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
+  int grid = ecg_bn_rows(dtype, M, C);
+  float* partial = scratch;
+  float* bcoef = scratch + (size_t)grid * 2 * C;
+  BnBwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.dout = dout; p.maskref = maskref; p.gate = gate; p.addc = addc; p.y = y; p.coef = coef; p.M = M; p.C = C;
+  p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+  p.partial = partial;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(EW_THREADS), 0, stream, p),
+             hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_bwd");
+  ECG_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, grid, C, (double)M,
+                     gamma, coef, dgamma, dbeta, bcoef);
+  ECG_CHECK_LAUNCH("bn_bwd_finalize");
+  if (!dy) return 0;
+  p.bcoef = bcoef; p.dy = dy; p.dz_out = dz_out;
+  p.partial = dbias ? partial : nullptr;  // reuse (finalize already consumed it; stream-ordered)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, true>), dim3(grid), dim3(EW_THREADS), 0, stream, p),
+             hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_bwd");
+  ECG_CHECK_LAUNCH("bn_bwd_apply");
+  if (dbias) {
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, partial, grid, C, dbias, 0);
+    ECG_CHECK_LAUNCH("rows_sum");
+  }
+  return 0;
+}
+
+int ecg_rows_sum(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, partial, rows, C, out, accumulate);
+  ECG_CHECK_LAUNCH("rows_sum");
+  return 0;
+}
+
+int ecg_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, unsigned char* idx, int N, int H, int W,
+                       int C, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "maxpool: C=%d unsupported", C);
+  int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  int grid = ew_grid((long)N * OH * OW * (C / vec), EW_THREADS);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bnrelu_maxpool_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, stream,
+                                (const bf16_t*)y, coef, (bf16_t*)out, idx, N, H, W, C, OH, OW),
+             hipLaunchKernelGGL(bnrelu_maxpool_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, stream, (const float*)y,
+                                coef, (float*)out, idx, N, H, W, C, OH, OW),
+             "maxpool");
+  ECG_CHECK_LAUNCH("bnrelu_maxpool");
+  return 0;
+}
+
+int ecg_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const unsigned char* idx, void* dz, int N,
+                         int H, int W, int C, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "maxpool bwd: C=%d unsupported", C);
+  int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  int grid = ew_grid((long)N * H * W * (C / vec), EW_THREADS);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool_relu_bwd_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, stream,
+                                (const bf16_t*)dp, (const bf16_t*)pooled, idx, (bf16_t*)dz, N, H, W, C, OH, OW),
+             hipLaunchKernelGGL(maxpool_relu_bwd_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, stream,
+                                (const float*)dp, (const float*)pooled, idx, (float*)dz, N, H, W, C, OH, OW),
+             "maxpool bwd");
+  ECG_CHECK_LAUNCH("maxpool_relu_bwd");
+  return 0;
+}
+
+int ecg_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, hipStream_t stream) {
+  dim3 grid(N, ceil_div(C, 64));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, R, C, coef),
+             hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, R, C, coef),
+             "avgpool");
+  ECG_CHECK_LAUNCH("avgpool");
+  return 0;
+}
+
+int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, hipStream_t stream) {
+  long total = (long)N * R * C;
+  int grid = ew_grid(total, 256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bcast_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, v, (bf16_t*)out, total, R,
+                                C, scale),
+             hipLaunchKernelGGL(bcast_rows_kernel<float>, dim3(grid), dim3(256), 0, stream, v, (float*)out, total, R, C,
+                                scale),
+             "bcast_rows");
+  ECG_CHECK_LAUNCH("bcast_rows");
+  return 0;
+}
+
+int ecg_se_gate_grad(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, float* dg,
+                     int N, int R, int C, hipStream_t stream) {
+  dim3 grid(N, ceil_div(C, 64));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(se_gate_grad_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)dout,
+                                (const bf16_t*)maskref, (const bf16_t*)y, coef, dg, R, C),
+             hipLaunchKernelGGL(se_gate_grad_kernel<float>, grid, dim3(256), 0, stream, (const float*)dout,
+                                (const float*)maskref, (const float*)y, coef, dg, R, C),
+             "se_gate_grad");
+  ECG_CHECK_LAUNCH("se_gate_grad");
+  return 0;
+}
+
+int ecg_pack_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int Cout, int Cin, int RS,
+                    hipStream_t stream) {
+  long total = (long)Cout * Cin * RS;
+  int grid = ew_grid(total, 256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, w_oihw, (bf16_t*)fwd,
+                                (bf16_t*)dgrad, Cout, Cin, RS),
+             hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, stream, w_oihw, (float*)fwd,
+                                (float*)dgrad, Cout, Cin, RS),
+             "pack_weight");
+  ECG_CHECK_LAUNCH("pack_weight");
+  return 0;
+}
+
+int ecg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, hipStream_t stream) {
+  dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((nchw_nhwc_kernel<bf16_t, true>), grid, dim3(256), 0, stream, src, dst, C, HW),
+             hipLaunchKernelGGL((nchw_nhwc_kernel<float, true>), grid, dim3(256), 0, stream, src, dst, C, HW),
+             "nchw_to_nhwc");
+  ECG_CHECK_LAUNCH("nchw_to_nhwc");
+  return 0;
+}
+
+int ecg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, hipStream_t stream) {
+  dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((nchw_nhwc_kernel<bf16_t, false>), grid, dim3(256), 0, stream, src, dst, C, HW),
+             hipLaunchKernelGGL((nchw_nhwc_kernel<float, false>), grid, dim3(256), 0, stream, src, dst, C, HW),
+             "nhwc_to_nchw");
+  ECG_CHECK_LAUNCH("nhwc_to_nchw");
+  return 0;
+}
+
+int ecg_cast(int dtype, const float* src, void* dst, long n, hipStream_t stream) {
+  int grid = ew_grid(n, 256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, n),
+             hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, stream, src, (float*)dst, n), "cast");
+  ECG_CHECK_LAUNCH("cast");
+  return 0;
+}
+int ecg_uncast(int dtype, const void* src, float* dst, long n, hipStream_t stream) {
+  int grid = ew_grid(n, 256);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(uncast_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, dst, n),
+             hipLaunchKernelGGL(uncast_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)src, dst, n),
+             "uncast");
+  ECG_CHECK_LAUNCH("uncast");
+  return 0;
+}

@@ -1,0 +1,99 @@
+// Internal (C++) launch interface between the kernel files, the encoder plans and the C-ABI layer.
+#pragma once
+#include "common.h"
+
+// conv_igemm.hip
+int ecg_conv_stats_rows(long M);
+int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst,
+                   const float* bias, const void* addend, float* stats, int act, hipStream_t stream);
+// conv_wgrad.hip
+size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g);
+int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, float* grad_oihw, int accumulate,
+                   void* workspace, size_t workspace_bytes, hipStream_t stream);
+// conv_stem.hip
+size_t ecg_stem_packed_elems(int Cin, int R);
+int ecg_stem_stats_rows(int N, int Cin, int H, int W, int R);
+int ecg_stem_pack(int dtype, const float* w, void* out, int Cin, int R, hipStream_t stream);
+int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
+                 int H, int W, int R, hipStream_t stream);
+size_t ecg_stem_wgrad_workspace(int N, int Cin, int H, int W, int R);
+int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int accumulate, void* workspace,
+                   size_t workspace_bytes, int N, int Cin, int H, int W, int R, hipStream_t stream);
+// elementwise.hip
+int ecg_bn_rows(int dtype, long M, int C);
+int ecg_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                    float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, hipStream_t stream);
+int ecg_bn_eval_coef(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                     float* coef, hipStream_t stream);
+int ecg_col_stats(int dtype, const void* x, long M, int C, float* partial, int* rows_out, hipStream_t stream);
+int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
+               int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream);
+size_t ecg_bn_bwd_scratch(int dtype, long M, int C);
+int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
+               int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma, float* dbeta,
+               void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream);
+int ecg_rows_sum(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t stream);
+int ecg_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, unsigned char* idx, int N, int H, int W,
+                       int C, hipStream_t stream);
+int ecg_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const unsigned char* idx, void* dz, int N,
+                         int H, int W, int C, hipStream_t stream);
+int ecg_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, hipStream_t stream);
+int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, hipStream_t stream);
+int ecg_se_gate_grad(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, float* dg,
+                     int N, int R, int C, hipStream_t stream);
+int ecg_pack_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int Cout, int Cin, int RS,
+                    hipStream_t stream);
+int ecg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, hipStream_t stream);
+int ecg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, hipStream_t stream);
+int ecg_cast(int dtype, const float* src, void* dst, long n, hipStream_t stream);
+int ecg_uncast(int dtype, const void* src, float* dst, long n, hipStream_t stream);
+// head.hip
+int ecg_linear_fwd_valu(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, int act,
+                        hipStream_t s);
+int ecg_linear_dgrad_valu(const float* dy, const float* w, float* dx, int B, int In, int Out, int accumulate,
+                          hipStream_t s);
+int ecg_linear_wgrad_valu(const float* dy, const float* x, float* dw, float* db, int B, int In, int Out,
+                          int accumulate, hipStream_t s);
+int ecg_act_bwd(const float* dy, const float* y, float* dz, long n, int act, hipStream_t s);
+int ecg_axpby(float a, const float* x, float b, float* y, long n, hipStream_t s);
+int ecg_layernorm_fwd(const float* const* seg, const int* dims, int nseg, const float* fusion_w, const float* gamma,
+                      const float* beta, float* out, float* stat, float* soft_w, int B, float eps, hipStream_t s);
+size_t ecg_layernorm_bwd_scratch(int B, int D);
+int ecg_layernorm_bwd(const float* const* seg, const int* dims, int nseg, const float* fusion_w, const float* gamma,
+                      const float* stat, const float* dout, float* const* dseg, int dseg_accumulate, float* dgamma,
+                      float* dbeta, float* dfusion_w, int B, float* scratch, hipStream_t s);
+int ecg_varloss_fwd(const float* f0, const float* f1, const float* f2, int B, int D0, int D1, int D2, float* loss,
+                    float* scratch, hipStream_t s);
+int ecg_varloss_bwd(const float* f, int B, int D, const float* gout, const float* scratch, int m, float* df,
+                    int accumulate, hipStream_t s);
+int ecg_ce_fwd(const float* logits, const long long* labels, int B, int C, int focal, float alpha, float gamma,
+               float* loss, float* dcoef, hipStream_t s);
+int ecg_ce_bwd(const float* logits, const long long* labels, int B, int C, const float* dcoef, const float* gout,
+               float* dlogits, hipStream_t s);
+int ecg_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed,
+                    unsigned long long offset, hipStream_t s);
+int ecg_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, hipStream_t s);
+int ecg_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd,
+             long step, float gscale, hipStream_t s);
+
+// linear.hip: fp32 Linear that picks the MFMA kernels when the shape allows, the VALU kernels otherwise
+size_t ecg_linear_bwd_scratch(int B, int In, int Out);
+int ecg_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, int act,
+                   float* stats, hipStream_t s);
+// dz is the gradient w.r.t. the pre-activation output; dx / dw / db may be null
+int ecg_linear_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* db, int B, int In,
+                   int Out, void* scratch, size_t scratch_bytes, hipStream_t s);
+
+// bump allocator over a caller-owned workspace (base == nullptr: measure only)
+struct Arena {
+  unsigned char* base;
+  size_t off;
+  explicit Arena(void* b) : base((unsigned char*)b), off(0) {}
+  template <typename T> T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+  void* take_bytes(size_t bytes) { return take<unsigned char>(bytes); }
+};

@@ -1,0 +1,334 @@
+// ResNet18 image encoder as a native launch plan (forward + backward), gfx950.
+// Mirrors torchvision.models.resnet18() as instantiated by the reference at
+// multimodal_paper_modal_balance.py:210,221 and train_image_only.py:92-99:
+//   conv7x7/2 -> BN -> ReLU -> maxpool3/2 -> 4 stages x 2 BasicBlocks -> global avgpool -> fc
+// Activations live channels-last in the compute dtype inside a caller-owned workspace; the image
+// enters as NCHW fp32 exactly as the reference's DataLoader hands it over.
+//
+// Parameter table order (62 entries, == named_parameters() order of the Python module):
+//   conv1.weight, bn1.weight, bn1.bias,
+//   layer{1..4}.{0,1}.{conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias,
+//                      [downsample.0.weight, downsample.1.weight, downsample.1.bias]},
+//   fc.weight, fc.bias
+// Buffer table order (60 entries): per BatchNorm in the same walk: running_mean, running_var,
+//   num_batches_tracked (int64).
+#include "ops.h"
+
+namespace {
+
+struct BlockCfg {
+  int cin, cout, stride, hin, win, hout, wout;
+  bool down;
+  int p_conv1, p_bn1, p_conv2, p_bn2, p_dconv, p_dbn;  // param indices (weight; bn bias = +1)
+  int b_bn1, b_bn2, b_dbn;                              // buffer indices (rm; rv = +1; nbt = +2)
+};
+
+struct R18 {
+  ecgmm_resnet18_desc d;
+  int H1, W1, H2, W2;
+  BlockCfg blk[8];
+  int p_fc;
+  size_t max_act;  // largest block-level activation (elements)
+};
+
+int build(const ecgmm_resnet18_desc* d, R18& r) {
+  if (!d) ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18: null desc");
+  if (d->dtype != ECGMM_BF16 && d->dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "resnet18: bad dtype %d", d->dtype);
+  if (d->N < 1 || d->H < 32 || d->W < 32) ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18: bad input %dx%dx%d", d->N, d->H, d->W);
+  r.d = *d;
+  r.H1 = (d->H + 6 - 7) / 2 + 1;
+  r.W1 = (d->W + 6 - 7) / 2 + 1;
+  r.H2 = (r.H1 + 2 - 3) / 2 + 1;
+  r.W2 = (r.W1 + 2 - 3) / 2 + 1;
+  int pi = 3, bi = 3, h = r.H2, w = r.W2, cin = 64;
+  r.max_act = 0;
+  for (int L = 0; L < 4; ++L) {
+    int cout = 64 << L;
+    for (int b = 0; b < 2; ++b) {
+      BlockCfg& k = r.blk[L * 2 + b];
+      k.cin = cin; k.cout = cout; k.stride = (b == 0 && L > 0) ? 2 : 1;
+      k.hin = h; k.win = w;
+      k.hout = (h + 2 - 3) / k.stride + 1;
+      k.wout = (w + 2 - 3) / k.stride + 1;
+      k.down = (k.stride != 1 || cin != cout);
+      k.p_conv1 = pi; k.p_bn1 = pi + 1; k.p_conv2 = pi + 3; k.p_bn2 = pi + 4; pi += 6;
+      k.b_bn1 = bi; k.b_bn2 = bi + 3; bi += 6;
+      if (k.down) {
+        k.p_dconv = pi; k.p_dbn = pi + 1; pi += 3;
+        k.b_dbn = bi; bi += 3;
+      } else {
+        k.p_dconv = k.p_dbn = k.b_dbn = -1;
+      }
+      size_t a = (size_t)d->N * k.hin * k.win * k.cin;
+      if (a > r.max_act) r.max_act = a;
+      a = (size_t)d->N * k.hout * k.wout * k.cout;
+      if (a > r.max_act) r.max_act = a;
+      h = k.hout; w = k.wout; cin = cout;
+    }
+  }
+  r.p_fc = pi;
+  if (pi + 2 != ECGMM_RESNET18_NPARAMS || bi != ECGMM_RESNET18_NBUFFERS)
+    ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18: internal table mismatch %d %d", pi + 2, bi);
+  return 0;
+}
+
+// saved-for-backward workspace
+struct FwdWs {
+  void* wstem;
+  void* y0; float* coef0; void* p0; unsigned char* idx0;
+  struct B {
+    void *w1f, *w1d, *w2f, *w2d, *wdf, *wdd;
+    void *y1, *a1, *y2, *yd, *out;
+    float *coef1, *coef2, *coefd;
+  } b[8];
+  float* pooled;
+  float* stats;  // transient partial-sum rows (largest layer)
+  size_t bytes;
+};
+
+void layout_fwd(const R18& r, void* base, FwdWs& w) {
+  Arena a(base);
+  const size_t es = dtype_size(r.d.dtype);
+  const int N = r.d.N;
+  w.wstem = a.take_bytes(ecg_stem_packed_elems(3, 7) * es);
+  w.y0 = a.take_bytes((size_t)N * r.H1 * r.W1 * 64 * es);
+  w.coef0 = a.take<float>(4 * 64);
+  w.p0 = a.take_bytes((size_t)N * r.H2 * r.W2 * 64 * es);
+  w.idx0 = a.take<unsigned char>((size_t)N * r.H2 * r.W2 * 64);
+  size_t max_rows_c = (size_t)ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7) * 2 * 64;
+  for (int i = 0; i < 8; ++i) {
+    const BlockCfg& k = r.blk[i];
+    FwdWs::B& b = w.b[i];
+    size_t osz = (size_t)N * k.hout * k.wout * k.cout;
+    b.w1f = a.take_bytes((size_t)k.cout * k.cin * 9 * es);
+    b.w1d = a.take_bytes((size_t)k.cout * k.cin * 9 * es);
+    b.w2f = a.take_bytes((size_t)k.cout * k.cout * 9 * es);
+    b.w2d = a.take_bytes((size_t)k.cout * k.cout * 9 * es);
+    b.y1 = a.take_bytes(osz * es);
+    b.a1 = a.take_bytes(osz * es);
+    b.y2 = a.take_bytes(osz * es);
+    b.out = a.take_bytes(osz * es);
+    b.coef1 = a.take<float>(4 * k.cout);
+    b.coef2 = a.take<float>(4 * k.cout);
+    if (k.down) {
+      b.wdf = a.take_bytes((size_t)k.cout * k.cin * es);
+      b.wdd = a.take_bytes((size_t)k.cout * k.cin * es);
+      b.yd = a.take_bytes(osz * es);
+      b.coefd = a.take<float>(4 * k.cout);
+    } else {
+      b.wdf = b.wdd = b.yd = nullptr;
+      b.coefd = nullptr;
+    }
+    size_t rows_c = (size_t)ecg_conv_stats_rows((long)N * k.hout * k.wout) * 2 * k.cout;
+    if (rows_c > max_rows_c) max_rows_c = rows_c;
+  }
+  w.pooled = a.take<float>((size_t)N * 512);
+  w.stats = a.take<float>(max_rows_c);
+  w.bytes = align_up(a.off, 256);
+}
+
+struct BwdWs {
+  void* X[2];   // gradient w.r.t. block outputs (ping-pong)
+  void* dz;     // masked residual-branch gradient
+  void* dy;     // gradient w.r.t. a raw conv output
+  void* da;     // gradient w.r.t. a1
+  void* dtmp;   // downsample-path input gradient
+  void* big0;   // stem: dz0
+  void* big1;   // stem: dy0
+  float* dpooled;
+  float* bn_scratch;
+  void* wg_ws; size_t wg_bytes;
+  void* lin_ws; size_t lin_bytes;
+  size_t bytes;
+};
+
+void layout_bwd(const R18& r, void* base, BwdWs& w) {
+  Arena a(base);
+  const size_t es = dtype_size(r.d.dtype);
+  const int N = r.d.N;
+  for (int i = 0; i < 2; ++i) w.X[i] = a.take_bytes(r.max_act * es);
+  w.dz = a.take_bytes(r.max_act * es);
+  w.dy = a.take_bytes(r.max_act * es);
+  w.da = a.take_bytes(r.max_act * es);
+  w.dtmp = a.take_bytes(r.max_act * es);
+  size_t big = (size_t)N * r.H1 * r.W1 * 64;
+  w.big0 = a.take_bytes(big * es);
+  w.big1 = a.take_bytes(big * es);
+  w.dpooled = a.take<float>((size_t)N * 512);
+  size_t bn = ecg_bn_bwd_scratch(r.d.dtype, (long)N * r.H1 * r.W1, 64);
+  size_t wg = ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);
+  for (int i = 0; i < 8; ++i) {
+    const BlockCfg& k = r.blk[i];
+    size_t s = ecg_bn_bwd_scratch(r.d.dtype, (long)N * k.hout * k.wout, k.cout);
+    if (s > bn) bn = s;
+    size_t g1 = ecg_conv_wgrad_workspace(r.d.dtype, make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1));
+    size_t g2 = ecg_conv_wgrad_workspace(r.d.dtype, make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1));
+    if (g1 > wg) wg = g1;
+    if (g2 > wg) wg = g2;
+    if (k.down) {
+      size_t g3 = ecg_conv_wgrad_workspace(r.d.dtype, make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0));
+      if (g3 > wg) wg = g3;
+    }
+  }
+  w.bn_scratch = (float*)a.take_bytes(bn);
+  w.wg_ws = a.take_bytes(wg);
+  w.wg_bytes = wg;
+  w.lin_bytes = ecg_linear_bwd_scratch(N, 512, r.d.out_dim);
+  w.lin_ws = a.take_bytes(w.lin_bytes);
+  w.bytes = align_up(a.off, 256);
+}
+
+inline const float* P(const void* const* params, int i) { return (const float*)params[i]; }
+inline float* G(void* const* grads, int i) { return grads ? (float*)grads[i] : nullptr; }
+
+// BN statistics of a fresh conv output -> coefficients (train: batch stats + running update; eval: running stats)
+int bn_coef(const R18& r, const float* stats, int rows, int C, long count, const void* const* params, int p_bn,
+            void* const* buffers, int b_bn, float* coef, hipStream_t s) {
+  if (r.d.training)
+    return ecg_bn_finalize(stats, rows, C, (double)count, P(params, p_bn), P(params, p_bn + 1), (float*)buffers[b_bn],
+                           (float*)buffers[b_bn + 1], (long long*)buffers[b_bn + 2], r.d.bn_momentum, r.d.bn_eps, coef,
+                           s);
+  return ecg_bn_eval_coef(C, P(params, p_bn), P(params, p_bn + 1), (const float*)buffers[b_bn],
+                          (const float*)buffers[b_bn + 1], r.d.bn_eps, coef, s);
+}
+
+}  // namespace
+
+extern "C" size_t ecgmm_resnet18_fwd_workspace(const ecgmm_resnet18_desc* d) {
+  R18 r;
+  if (build(d, r)) return 0;
+  FwdWs w;
+  layout_fwd(r, nullptr, w);
+  return w.bytes;
+}
+
+extern "C" size_t ecgmm_resnet18_bwd_workspace(const ecgmm_resnet18_desc* d) {
+  R18 r;
+  if (build(d, r)) return 0;
+  BwdWs w;
+  layout_bwd(r, nullptr, w);
+  return w.bytes;
+}
+
+extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float* image, const void* const* params,
+                                      void* const* buffers, float* feat_out, void* ws, size_t ws_bytes,
+                                      void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  R18 r;
+  ECG_TRY(build(d, r));
+  FwdWs w;
+  layout_fwd(r, ws, w);
+  if (!ws || ws_bytes < w.bytes) ECG_FAIL(ECGMM_ERR_WORKSPACE, "resnet18 fwd: workspace %zu < %zu", ws_bytes, w.bytes);
+  const int dt = r.d.dtype, N = r.d.N;
+  const int stats_rows = r.d.training ? 1 : 0;
+
+  // ---- stem
+  ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, 3, 7, s));
+  ECG_TRY(ecg_stem_fwd(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
+  ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
+                  buffers, 0, w.coef0, s));
+  ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
+
+  const void* cur = w.p0;
+  for (int i = 0; i < 8; ++i) {
+    const BlockCfg& k = r.blk[i];
+    FwdWs::B& b = w.b[i];
+    const long M = (long)N * k.hout * k.wout;
+    const int rows = ecg_conv_stats_rows(M);
+    ConvGeom g1 = make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1);
+    ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
+    ECG_TRY(ecg_pack_weight(dt, P(params, k.p_conv1), b.w1f, b.w1d, k.cout, k.cin, 9, s));
+    ECG_TRY(ecg_pack_weight(dt, P(params, k.p_conv2), b.w2f, b.w2d, k.cout, k.cout, 9, s));
+    ECG_TRY(ecg_conv_igemm(dt, 0, g1, cur, b.w1f, b.y1, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
+    ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_bn1, buffers, k.b_bn1, b.coef1, s));
+    ECG_TRY(ecg_bn_act(dt, b.y1, b.coef1, nullptr, nullptr, nullptr, 1, 1, b.a1, M, k.cout, s));
+    ECG_TRY(ecg_conv_igemm(dt, 0, g2, b.a1, b.w2f, b.y2, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
+    ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, s));
+    if (k.down) {
+      ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
+      ECG_TRY(ecg_pack_weight(dt, P(params, k.p_dconv), b.wdf, b.wdd, k.cout, k.cin, 1, s));
+      ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
+      ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_dbn, buffers, k.b_dbn, b.coefd, s));
+      ECG_TRY(ecg_bn_act(dt, b.y2, b.coef2, b.yd, b.coefd, nullptr, 1, 1, b.out, M, k.cout, s));
+    } else {
+      ECG_TRY(ecg_bn_act(dt, b.y2, b.coef2, cur, nullptr, nullptr, 1, 1, b.out, M, k.cout, s));
+    }
+    cur = b.out;
+  }
+  const BlockCfg& last = r.blk[7];
+  ECG_TRY(ecg_avgpool(dt, cur, w.pooled, N, last.hout * last.wout, 512, nullptr, s));
+  ECG_TRY(ecg_linear_fwd(w.pooled, P(params, r.p_fc), P(params, r.p_fc + 1), feat_out, N, 512, r.d.out_dim, 0, nullptr,
+                         s));
+  return 0;
+}
+
+// stages: 0 = fc + avgpool, 1..8 = blocks 7..0, 9 = stem.  Run [stage_begin, stage_end).
+extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float* image, const float* dfeat,
+                                       const void* const* params, void* const* grads, void* ws_fwd, void* ws_bwd,
+                                       size_t ws_bwd_bytes, int stage_begin, int stage_end, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  R18 r;
+  ECG_TRY(build(d, r));
+  if (!r.d.training) ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: forward ran in eval mode (no batch statistics saved)");
+  FwdWs w;
+  layout_fwd(r, ws_fwd, w);
+  BwdWs q;
+  layout_bwd(r, ws_bwd, q);
+  if (!ws_fwd || !ws_bwd || ws_bwd_bytes < q.bytes)
+    ECG_FAIL(ECGMM_ERR_WORKSPACE, "resnet18 bwd: workspace %zu < %zu", ws_bwd_bytes, q.bytes);
+  const int dt = r.d.dtype, N = r.d.N;
+
+  for (int st = stage_begin; st < stage_end; ++st) {
+    if (st == 0) {
+      const BlockCfg& last = r.blk[7];
+      ECG_TRY(ecg_linear_bwd(dfeat, w.pooled, P(params, r.p_fc), q.dpooled, G(grads, r.p_fc), G(grads, r.p_fc + 1), N,
+                             512, r.d.out_dim, q.lin_ws, q.lin_bytes, s));
+      const int R = last.hout * last.wout;
+      ECG_TRY(ecg_bcast_rows(dt, q.dpooled, q.X[0], N, R, 512, 1.f / (float)R, s));
+    } else if (st <= 8) {
+      const int i = 8 - st;
+      const BlockCfg& k = r.blk[i];
+      FwdWs::B& b = w.b[i];
+      const void* in = i == 0 ? w.p0 : w.b[i - 1].out;
+      const void* dcur = q.X[(st - 1) & 1];
+      void* din = q.X[st & 1];
+      const long M = (long)N * k.hout * k.wout;
+      ConvGeom g1 = make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1);
+      ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
+      // out = relu(bn2(y2) + identity)
+      ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, nullptr, nullptr, 1, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
+                         G(grads, k.p_bn2 + 1), q.dy, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
+      if (G(grads, k.p_conv2))
+        ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, s));
+      ECG_TRY(ecg_conv_igemm(dt, 1, g2, q.dy, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
+      // a1 = relu(bn1(y1))
+      ECG_TRY(ecg_bn_bwd(dt, q.da, b.a1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
+                         G(grads, k.p_bn1 + 1), q.dy, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
+      if (G(grads, k.p_conv1))
+        ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, s));
+      if (k.down) {
+        ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
+        // q.da is free again: use it for the downsample branch's conv-output gradient
+        ECG_TRY(ecg_bn_bwd(dt, q.dz, nullptr, nullptr, nullptr, 1, b.yd, b.coefd, P(params, k.p_dbn),
+                           G(grads, k.p_dbn), G(grads, k.p_dbn + 1), q.da, nullptr, nullptr, M, k.cout, q.bn_scratch,
+                           s));
+        if (G(grads, k.p_dconv))
+          ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.da, G(grads, k.p_dconv), 0, q.wg_ws, q.wg_bytes, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.da, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+      } else {
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
+      }
+    } else if (st == 9) {
+      const void* dp0 = q.X[8 & 1];
+      ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, r.H1, r.W1, 64, s));
+      ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 1), G(grads, 1),
+                         G(grads, 2), q.big1, nullptr, nullptr, (long)N * r.H1 * r.W1, 64, q.bn_scratch, s));
+      if (G(grads, 0))
+        ECG_TRY(ecg_stem_wgrad(dt, image, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, 3, r.d.H, r.d.W, 7, s));
+    } else {
+      ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: stage %d out of range", st);
+    }
+  }
+  return 0;
+}

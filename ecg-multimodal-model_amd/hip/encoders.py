@@ -1,0 +1,108 @@
+"""Encoder-level autograd Functions: one C-ABI call runs a whole ResNet18 / ResNet1D_SE forward (or a
+range of backward stages) as a native launch plan (csrc/plan_resnet18.hip, plan_resnet1d.hip)."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .functional import _Scratch, _require_cuda, f32c, grad_sink, new_bytes, ptr, stream, vp, _PhiloxState
+
+DTYPES = {"bf16": L.BF16, "bfloat16": L.BF16, "fp32": L.F32, "float32": L.F32, "f32": L.F32}
+
+
+def dtype_code(name):
+    try:
+        return DTYPES[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"compute dtype must be 'bf16' or 'fp32', got {name!r}")
+
+
+def _table(tensors):
+    return (vp * len(tensors))(*[None if t is None else vp(t.data_ptr()) for t in tensors])
+
+
+class _PlanFn(torch.autograd.Function):
+    """Shared forward/backward driver.  ``spec`` supplies the C entry points and the descriptor."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        _require_cuda(x, spec.name)
+        for p in params:
+            _require_cuda(p, spec.name + " parameter")
+        x = f32c(x)
+        lib = L.lib()
+        desc = spec.make_desc(x)
+        ws_bytes = getattr(lib, spec.prefix + "_fwd_workspace")(C.byref(desc))
+        if ws_bytes == 0:
+            L.check(1, spec.name + " workspace query")
+        ws = new_bytes(ws_bytes, x.device)
+        feat = torch.empty(x.shape[0], spec.out_dim, device=x.device, dtype=torch.float32)
+        ptab = _table(params)
+        btab = _table(spec.buffers)
+        L.check(getattr(lib, spec.prefix + "_forward")(C.byref(desc), ptr(x), ptab, btab, ptr(feat), ptr(ws),
+                                                        ws.numel(), stream()), spec.name + " forward")
+        ctx.spec, ctx.desc, ctx.ws, ctx.x, ctx.params = spec, desc, ws, x, params
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        spec, desc = ctx.spec, ctx.desc
+        if not desc.training:
+            raise RuntimeError(f"{spec.name}: backward through an eval-mode forward is not supported")
+        lib = L.lib()
+        dfeat = f32c(dfeat)
+        ptab = _table(ctx.params)
+        gtab = _table([grad_sink(p) for p in ctx.params])
+        nb = getattr(lib, spec.prefix + "_bwd_workspace")(C.byref(desc))
+        bws = _Scratch.get(spec.prefix + "_bwd", nb, dfeat.device)
+        fn = getattr(lib, spec.prefix + "_backward")
+        stages = spec.stage_groups or [(0, spec.n_stages)]
+        for gi, (b, e) in enumerate(stages):
+            L.check(fn(C.byref(desc), ptr(ctx.x), ptr(dfeat), ptab, gtab, ptr(ctx.ws), ptr(bws), bws.numel(), b, e,
+                       stream()), spec.name + " backward")
+            if spec.stage_hook is not None:
+                spec.stage_hook(spec, gi)
+        ctx.ws = None
+        return (None, None) + (None,) * len(ctx.params)
+
+
+class PlanSpec:
+    """Mutable per-module launch description (rebuilt cheaply every forward)."""
+    stage_groups = None   # list of (begin, end) backward stage ranges (set by parallel.py for overlap)
+    stage_hook = None     # callable(spec, group_index) fired after each group
+
+    def __init__(self, name, prefix, n_stages):
+        self.name, self.prefix, self.n_stages = name, prefix, n_stages
+        self.buffers = []
+        self.out_dim = 0
+
+
+class ResNet18Spec(PlanSpec):
+    def __init__(self):
+        super().__init__("resnet18", "ecgmm_resnet18", 10)
+        self.dtype, self.training, self.momentum, self.eps = L.BF16, True, 0.1, 1e-5
+
+    def make_desc(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"image encoder expects [B,3,H,W], got {tuple(x.shape)}")
+        return L.ResNet18Desc(x.shape[0], x.shape[2], x.shape[3], self.out_dim, self.dtype, int(self.training),
+                              self.momentum, self.eps)
+
+
+class ResNet1DSpec(PlanSpec):
+    def __init__(self):
+        super().__init__("resnet1d_se", "ecgmm_resnet1d", 5)
+        self.dtype, self.training, self.momentum, self.eps = L.BF16, True, 0.1, 1e-5
+        self.dropout_p, self.cin = 0.3, 1
+
+    def make_desc(self, x):
+        if x.dim() != 3 or x.shape[1] != self.cin:
+            raise ValueError(f"signal encoder expects [B,{self.cin},L], got {tuple(x.shape)}")
+        p = self.dropout_p if self.training else 0.0
+        seed, off = _PhiloxState.take(x.shape[0] * 64) if p > 0 else (0, 0)
+        return L.ResNet1DDesc(x.shape[0], self.cin, x.shape[2], self.out_dim, self.dtype, int(self.training),
+                              self.momentum, self.eps, p, seed, off)
+
+
+def run_plan(x, spec, params):
+    return _PlanFn.apply(x, spec, *params)

@@ -1,0 +1,141 @@
+"""Data parallelism for the multimodal step: one process per GPU, per-patient batch sharded across
+ranks, gradients summed by RCCL (``torch.distributed`` backend "nccl" on ROCm) over xGMI.
+
+The reference has no distributed code at all; this is the one collective the MI355X build adds
+(SURVEY 8e).  Design for xGMI (point-to-point links, per-link-bound rings): all gradients live in ONE
+flat fp32 buffer (``flatten``), reduced in a few large buckets on a side stream while the remaining
+backward stages still run (``DataParallel`` installs backward-stage hooks on the encoder plans), and
+the 1/world scale is folded into the fused Adam (``grad_scale``) instead of a separate pass.
+BatchNorm statistics stay per replica, as torch DDP does.
+"""
+import torch
+import torch.distributed as dist
+
+
+def flatten(model, only_trainable=True):
+    """Re-point every (trainable) parameter and its gradient at slices of two flat fp32 buffers.
+    Returns (flat_params, flat_grads).  Order = model.parameters() order."""
+    params = [p for p in model.parameters() if (p.requires_grad or not only_trainable)]
+    if not params:
+        return None, None
+    dev = params[0].device
+    total = sum(p.numel() for p in params)
+    # pad each tensor to a multiple of 4 elements so every view stays 16-byte aligned
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+    flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+    with torch.no_grad():
+        for p, o in zip(params, offs):
+            n = p.numel()
+            flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat_p[o:o + n].view(p.shape)
+            gv = flat_g[o:o + n].view(p.shape)
+            p._ecg_grad_view = gv
+            p.grad = gv
+    model._ecg_flat = (flat_p, flat_g, params, offs)
+    return flat_p, flat_g
+
+
+class DataParallel(torch.nn.Module):
+    """Minimal DDP: broadcast initial parameters from rank 0, then ``reduce_gradients()`` after (or,
+    with ``overlap=True``, during) backward.  Gradients are SUMMED; pass ``grad_scale=1/world`` to
+    FusedAdam (``self.grad_scale``)."""
+
+    def __init__(self, module, process_group=None, bucket_mb=32, overlap=True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.grad_scale = 1.0 / self.world
+        if getattr(module, "_ecg_flat", None) is None:
+            flatten(module)
+        self.flat_p, self.flat_g, self._params, self._offs = module._ecg_flat
+        self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
+        self._pending = []
+        self._comm_stream = None
+        self.overlap = overlap and self.world > 1 and self.flat_g.is_cuda
+        if self.world > 1:
+            dist.broadcast(self.flat_p, src=0, group=self.pg)
+            for b in module.buffers():
+                dist.broadcast(b, src=0, group=self.pg)
+        if self.overlap:
+            self._comm_stream = torch.cuda.Stream()
+            self._install_hooks()
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    # -- gradient ranges ------------------------------------------------------------------------
+    def _range_of(self, params):
+        idx = {id(p): i for i, p in enumerate(self._params)}
+        ids = [idx[id(p)] for p in params if id(p) in idx]
+        if not ids:
+            return None
+        lo, hi = min(ids), max(ids)
+        return self._offs[lo], self._offs[hi] + (self._params[hi].numel() + 3) // 4 * 4
+
+    def _install_hooks(self):
+        """Split the image encoder's backward into stage groups; after each group its finished
+        gradient range is all-reduced on the comm stream while earlier layers still compute."""
+        enc = getattr(self.module, "image_encoder", None)
+        if enc is None or not hasattr(enc, "_spec"):
+            return
+        groups = [(0, 3), (3, 5), (5, 10)]           # fc+layer4 | layer3 | layer2, layer1, stem
+        owners = [[enc.fc, enc.layer4], [enc.layer3], [enc.layer2, enc.layer1, enc.conv1, enc.bn1]]
+        ranges = []
+        for mods in owners:
+            ps = [p for m in mods for p in m.parameters() if p.requires_grad]
+            ranges.append(self._range_of(ps))
+        self._enc_ranges = ranges
+        enc._spec.stage_groups = groups
+        enc._spec.stage_hook = self._stage_hook
+
+    def _stage_hook(self, spec, gi):
+        r = self._enc_ranges[gi]
+        if r is not None:
+            self._launch(r[0], r[1])
+            self._done_ranges.append(r)
+
+    def _launch(self, lo, hi):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ev)
+            pos = lo
+            while pos < hi:
+                end = min(hi, pos + self.bucket_elems)
+                dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg)
+                pos = end
+
+    def prepare_backward(self):
+        self._done_ranges = []
+
+    def reduce_gradients(self):
+        """All-reduce whatever the stage hooks have not already shipped, then make the compute
+        stream wait for the comm stream."""
+        if self.world == 1:
+            return
+        done = sorted(getattr(self, "_done_ranges", []))
+        total = self.flat_g.numel()
+        todo, pos = [], 0
+        for lo, hi in done:
+            if lo > pos:
+                todo.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < total:
+            todo.append((pos, total))
+        if self.overlap:
+            for lo, hi in todo:
+                self._launch(lo, hi)
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        else:
+            for lo, hi in todo:
+                p = lo
+                while p < hi:
+                    e = min(hi, p + self.bucket_elems)
+                    dist.all_reduce(self.flat_g[p:e], op=dist.ReduceOp.SUM, group=self.pg)
+                    p = e
+        self._done_ranges = []

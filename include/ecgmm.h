@@ -1,0 +1,208 @@
+/* libecgmm_hip.so -- C ABI of the MI355X (gfx950) multimodal ECG hot path.
+ *
+ * The reference (hyeeiin/ECG-Multimodal-Model) is pure PyTorch and has no FFI; the boundary this
+ * library sits behind is the torch.nn.Module / autograd contract of its model classes.  Each entry
+ * point below therefore names the reference torch call it replaces (paths relative to the reference
+ * tree; "PMB" = multimodal_paper_modal_balance.py).  The Python host (ecg-multimodal-model_amd/)
+ * binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; the caller (PyTorch) owns ALL memory.  No entry point
+ *     allocates, frees, synchronises or retains a pointer after it returns.
+ *   - every function enqueues on the hipStream_t passed as `stream` (void*; 0 = default stream).
+ *   - return 0 on success, an ECGMM_ERR_* code otherwise; ecgmm_last_error() gives the message
+ *     (thread-local).  The Python wrapper raises RuntimeError.
+ *   - activations are channels-last ([N,H,W,C] / [N,L,C]) in the compute dtype (ECGMM_BF16 or
+ *     ECGMM_F32); parameters, statistics, gradients and the dense tails are fp32.
+ */
+#ifndef ECGMM_H
+#define ECGMM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECGMM_VERSION 100
+
+enum { ECGMM_F32 = 0, ECGMM_BF16 = 1 };
+enum { ECGMM_ACT_NONE = 0, ECGMM_ACT_RELU = 1, ECGMM_ACT_SIGMOID = 2 };
+enum {
+  ECGMM_OK = 0,
+  ECGMM_ERR_SHAPE = 1,
+  ECGMM_ERR_DTYPE = 2,
+  ECGMM_ERR_WORKSPACE = 3,
+  ECGMM_ERR_LAUNCH = 4
+};
+
+int ecgmm_version(void);
+const char* ecgmm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder plans (the product path: one call = one encoder forward / backward)
+ * ------------------------------------------------------------------------------------------- */
+#define ECGMM_RESNET18_NPARAMS 62
+#define ECGMM_RESNET18_NBUFFERS 60
+typedef struct {
+  int N, H, W;      /* image batch, NCHW fp32 */
+  int out_dim;      /* fc out_features (PMB:221 -> image_dim; train_image_only.py:96 -> num_classes) */
+  int dtype;        /* trunk compute dtype */
+  int training;     /* BatchNorm batch statistics + running-stat update (model.train(), train.py:57) */
+  float bn_momentum, bn_eps;
+} ecgmm_resnet18_desc;
+
+/* replaces self.image_encoder(image) -- torchvision resnet18 instantiated at PMB:210, called PMB:325;
+ * ImageOnlyClassifier.forward, train_image_only.py:98 */
+size_t ecgmm_resnet18_fwd_workspace(const ecgmm_resnet18_desc* d);
+size_t ecgmm_resnet18_bwd_workspace(const ecgmm_resnet18_desc* d);
+int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float* image, const void* const* params,
+                           void* const* buffers, float* feat_out, void* ws, size_t ws_bytes, void* stream);
+/* replaces the image-encoder part of total_loss.backward() (train.py:80, train_image_only.py:131).
+ * grads[i] == NULL skips that parameter (requires_grad=False, train.py:35-40). Gradients are WRITTEN
+ * (not accumulated).  stages [begin,end): 0 = fc+avgpool, 1..8 = blocks 7..0, 9 = stem -- the split
+ * lets the host launch a gradient all-reduce bucket between stages. */
+int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float* image, const float* dfeat,
+                            const void* const* params, void* const* grads, void* ws_fwd, void* ws_bwd,
+                            size_t ws_bwd_bytes, int stage_begin, int stage_end, void* stream);
+
+#define ECGMM_RESNET1D_NPARAMS 52
+#define ECGMM_RESNET1D_NBUFFERS 27
+typedef struct {
+  int N, cin, L;        /* signal batch [N, cin, L] fp32 (ecg_signal.unsqueeze(1), PMB:328) */
+  int num_classes;      /* classifier[4] out_features (PMB:226 -> signal_dim) */
+  int dtype;
+  int training;
+  float bn_momentum, bn_eps;
+  float dropout_p;      /* classifier[3] = Dropout(0.3), PMB:115; applied only when training */
+  uint64_t seed, offset;
+} ecgmm_resnet1d_desc;
+
+/* replaces ResNet1D_SE.forward (PMB:119-125; signal_model.py:82-88; train_signal_12_af.py:204-210) */
+size_t ecgmm_resnet1d_fwd_workspace(const ecgmm_resnet1d_desc* d);
+size_t ecgmm_resnet1d_bwd_workspace(const ecgmm_resnet1d_desc* d);
+int ecgmm_resnet1d_forward(const ecgmm_resnet1d_desc* d, const float* signal, const void* const* params,
+                           void* const* buffers, float* feat_out, void* ws, size_t ws_bytes, void* stream);
+/* stages: 0 = classifier+avgpool, 1..3 = layer3..layer1, 4 = stem */
+int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float* signal, const float* dfeat,
+                            const void* const* params, void* const* grads, void* ws_fwd, void* ws_bwd,
+                            size_t ws_bwd_bytes, int stage_begin, int stage_end, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-op entry points (building blocks of the plans; also what the parity tests call one by one)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int N, H, W, Cin, Cout, R, S, stride, pad_h, pad_w;
+} ecgmm_conv_desc;
+
+/* layout helpers (the reference's tensors are NCHW / OIHW) */
+int ecgmm_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int64_t HW, void* stream);
+int ecgmm_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int64_t HW, void* stream);
+int ecgmm_cast(int dtype, const float* src, void* dst, int64_t n, void* stream);
+int ecgmm_uncast(int dtype, const void* src, float* dst, int64_t n, void* stream);
+/* OIHW fp32 -> forward pack [Cout][R*S][Cin] and/or dgrad pack [Cin][R*S][Cout] (either may be NULL) */
+int ecgmm_pack_conv_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int Cout, int Cin, int RS,
+                           void* stream);
+
+/* nn.Conv2d / nn.Conv1d forward (F.conv2d inside torchvision BasicBlock; PMB:71,74,81 Conv1d).
+ * stats (nullable): partial BatchNorm sums, ecgmm_conv_stats_rows(N*OH*OW) rows of [2][Cout]. */
+int ecgmm_conv_stats_rows(int64_t out_pixels);
+int ecgmm_conv_fwd(int dtype, const ecgmm_conv_desc* c, const void* x, const void* w_fwd, const float* bias, void* y,
+                   float* stats, int act, void* stream);
+/* autograd of the above: input gradient (addend, nullable, is added to dx) and weight gradient */
+int ecgmm_conv_bwd_data(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad, const void* addend,
+                        void* dx, void* stream);
+size_t ecgmm_conv_bwd_weight_workspace(int dtype, const ecgmm_conv_desc* c);
+int ecgmm_conv_bwd_weight(int dtype, const ecgmm_conv_desc* c, const void* x, const void* dy, float* dw_oihw,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* stem convolutions straight from NCHW / NCL fp32 input: resnet18.conv1 (R = 7) and
+ * ResNet1D_SE.initial[0] (R = 1, H = 1; PMB:100) */
+size_t ecgmm_stem_packed_elems(int Cin, int R);
+int ecgmm_stem_stats_rows(int N, int Cin, int H, int W, int R);
+int ecgmm_stem_pack(int dtype, const float* w_oihw, void* packed, int Cin, int R, void* stream);
+int ecgmm_stem_fwd(int dtype, const float* x, const void* packed, const float* bias, void* y, float* stats, int N,
+                   int Cin, int H, int W, int R, void* stream);
+size_t ecgmm_stem_bwd_weight_workspace(int N, int Cin, int H, int W, int R);
+int ecgmm_stem_bwd_weight(int dtype, const float* x, const void* dy, float* dw_oihw, int accumulate, void* ws,
+                          size_t ws_bytes, int N, int Cin, int H, int W, int R, void* stream);
+
+/* nn.BatchNorm{1,2}d (train: batch mean / biased var, running update with unbiased var; eval: running
+ * stats).  coef = [4][C]: scale, shift, mean, invstd. */
+int ecgmm_col_stats_rows(int dtype, int64_t M, int C);
+int ecgmm_col_stats(int dtype, const void* x, int64_t M, int C, float* partial, void* stream);
+int ecgmm_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                      float* coef, void* stream);
+int ecgmm_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* coef, void* stream);
+/* out = relu?( bn(y) * gate[n][c] + residual ), residual = res or res*rcoef.scale + rcoef.shift
+ * (BasicBlock tail; BasicBlock1D tail with the SE gate, PMB:88-93) */
+int ecgmm_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
+                 int rows_per_sample, int relu, void* out, int64_t M, int C, void* stream);
+/* BatchNorm backward with the ReLU mask / SE gate folded in:
+ *   dz = [maskref > 0] * dout * gate[n][c] + addc[n][c];  dy, dgamma, dbeta; dz_out = masked dout;
+ *   dbias (nullable) = column sum of dy (Conv1d bias gradient). scratch: ecgmm_bn_bwd_scratch bytes */
+size_t ecgmm_bn_bwd_scratch(int dtype, int64_t M, int C);
+int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
+                 int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma,
+                 float* dbeta, void* dy, void* dz_out, float* dbias, int64_t M, int C, void* scratch, void* stream);
+
+/* relu(bn(y)) -> MaxPool(3,2,1) (resnet18.maxpool; ResNet1D_SE.initial[3], PMB:103) and its backward */
+int ecgmm_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int N, int H, int W,
+                         int C, void* stream);
+int ecgmm_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const uint8_t* idx, void* dz, int N, int H,
+                           int W, int C, void* stream);
+/* AdaptiveAvgPool(1) (+ optional per-channel affine of the mean) and its broadcast backward */
+int ecgmm_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, void* stream);
+int ecgmm_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, void* stream);
+int ecgmm_se_gate_grad(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, float* dg,
+                       int N, int R, int C, void* stream);
+
+/* nn.Linear (+bias, +ReLU/Sigmoid) fp32: MFMA (exact f32) when the shape allows, VALU otherwise.
+ * (clinical_encoder PMB:256-262, fusion_classifier PMB:283-289, branch heads PMB:269-271, SE fc PMB:53-58) */
+int ecgmm_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, int act,
+                     void* stream);
+size_t ecgmm_linear_bwd_scratch(int B, int In, int Out);
+int ecgmm_linear_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* db, int B, int In,
+                     int Out, void* scratch, size_t scratch_bytes, void* stream);
+int ecgmm_act_bwd(const float* dy, const float* y, float* dz, int64_t n, int act, void* stream);
+
+/* nn.LayerNorm (PMB:223,239,263) and AttentionFusion (PMB:31-46): softmax(weights) * feats -> cat ->
+ * LayerNorm, one row kernel.  nseg = 1 (plain LN, fusion_w = NULL) or 3 (fusion). stat = [B][2]. */
+int ecgmm_layernorm_fwd(const float* const* seg, const int* dims, int nseg, const float* fusion_w, const float* gamma,
+                        const float* beta, float* out, float* stat, float* soft_w, int B, float eps, void* stream);
+size_t ecgmm_layernorm_bwd_scratch(int B, int D);
+int ecgmm_layernorm_bwd(const float* const* seg, const int* dims, int nseg, const float* fusion_w, const float* gamma,
+                        const float* stat, const float* dout, float* const* dseg, int dseg_accumulate, float* dgamma,
+                        float* dbeta, float* dfusion_w, int B, void* scratch, void* stream);
+
+/* var_loss (PMB:349-352). scratch = (3*B + 4) floats, kept for the backward */
+int ecgmm_varloss_fwd(const float* f0, const float* f1, const float* f2, int B, int D0, int D1, int D2, float* loss,
+                      float* scratch, void* stream);
+int ecgmm_varloss_bwd(const float* f, int B, int D, const float* gout, const float* scratch, int which, float* df,
+                      int accumulate, void* stream);
+
+/* nn.CrossEntropyLoss() (train.py:31) / FocalLoss (signal_model.py:91-106), mean reduction.
+ * dcoef = [B] floats kept for the backward; labels are int64 */
+int ecgmm_ce_fwd(const float* logits, const int64_t* labels, int B, int C, int focal, float alpha, float gamma,
+                 float* loss, float* dcoef, void* stream);
+int ecgmm_ce_bwd(const float* logits, const int64_t* labels, int B, int C, const float* dcoef, const float* gout,
+                 float* dlogits, void* stream);
+
+/* nn.Dropout (PMB:115,260,287): Philox4x32-10, keep-mask bytes saved for the backward */
+int ecgmm_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                      void* stream);
+int ecgmm_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+
+/* torch.optim.Adam.step (train.py:43,81; betas/eps defaults; beta1 varies under OneCycleLR,
+ * train_signal_12_af.py:250-252) over one contiguous fp32 run; gscale multiplies the gradient
+ * (1/world_size after a summed all-reduce) */
+int ecgmm_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int64_t step, float gscale, void* stream);
+int ecgmm_axpby(float a, const float* x, float b, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGMM_H */

@@ -1,0 +1,193 @@
+"""End-to-end parity of the encoder plans and the full multimodal model against the CPU oracle
+(oracle/ref_models.py) and the committed goldens.  fp32 compute: logits within 1e-3 (north_star);
+bf16 compute: stated looser tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from ecgmm.config import Config
+from ecgmm.hip import functional as HF
+from ecgmm.image_encoder import ResNet18
+from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel, ResNet1D_SE
+from ecgmm.optim import FusedAdam
+from oracle import fill, ref_models as O
+
+from .util import DEV, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _disable_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def _grads(model):
+    return {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def _compare_grads(mine, ref, tol, skip=()):
+    gm, bad = _grads(mine), []
+    for k, p in ref.named_parameters():
+        if p.grad is None or any(s in k for s in skip):
+            continue
+        e = rel_err(gm[k], p.grad)
+        if not e < tol:
+            bad.append((k, e))
+    assert not bad, bad
+
+
+# Conv1d biases feed straight into BatchNorm: their true gradient is exactly zero and both sides
+# produce rounding noise, so they are excluded from relative comparisons (checked absolutely below).
+SIG_BIAS_SKIP = ("initial.0.bias", "conv1.bias", "conv2.bias", "downsample.0.bias")
+
+
+@pytest.mark.parametrize("cd,tol_out,tol_grad", [("fp32", 2e-4, 2e-3), ("bf16", 0.08, 0.12)])
+def test_resnet1d_ptbxl_train_step_vs_reference_golden(golden_dir, cd, tol_out, tol_grad):
+    """g2 was produced by the REFERENCE's ResNet1D_SE class with the reference's best_ptbxl.pth."""
+    g2 = np.load(f"{golden_dir}/g2_ptbxl_train.npz")
+    sd = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/best_ptbxl_tensors.npz").items()}
+    net = ResNet1D_SE(1, 2, compute_dtype=cd)
+    net.load_state_dict(sd, strict=True)
+    net = _disable_dropout(net).to(DEV).train()
+    x = dev(fill.hash_tensor((4, 1, 2476), 91, 1.5))
+    y = dev(torch.tensor([0, 1, 1, 0]))
+    logits = net(x)
+    loss = HF.cross_entropy(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (logits.detach().cpu() - torch.from_numpy(g2["logits"])).abs().max() < tol_out
+    assert abs(loss.item() - float(g2["loss"])) < tol_out
+    bad = []
+    for k, p in net.named_parameters():
+        ref = torch.from_numpy(g2["grad." + k])
+        if any(s in k for s in SIG_BIAS_SKIP):
+            assert p.grad.abs().max().item() < (1e-3 if cd == "fp32" else 0.5), k
+            continue
+        e = rel_err(p.grad.cpu(), ref)
+        if not e < tol_grad:
+            bad.append((k, e))
+    assert not bad, bad
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            assert torch.allclose(v.cpu(), torch.from_numpy(g2["buf." + k]), rtol=5e-3 if cd == "fp32" else 0.05,
+                                  atol=1e-4 if cd == "fp32" else 5e-3), k
+
+
+def test_resnet1d_eval_vs_reference_golden(golden_dir):
+    g1 = np.load(f"{golden_dir}/g1_ptbxl_eval.npz")
+    sd = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/best_ptbxl_tensors.npz").items()}
+    net = ResNet1D_SE(1, 2, compute_dtype="fp32")
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    for Ln in (2476, 5000):
+        x = dev(fill.hash_tensor((4, 1, Ln), 77 + Ln, 1.5))
+        with torch.no_grad():
+            out = net(x)
+        assert (out.cpu() - torch.from_numpy(g1[f"logits_{Ln}"])).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("cd,tol_out,tol_grad", [("fp32", 1e-3, 5e-3), ("bf16", 0.1, 0.15)])
+@pytest.mark.parametrize("shape", [(4, 3, 64, 64), (2, 3, 96, 160)])
+def test_resnet18_train_vs_oracle(cd, tol_out, tol_grad, shape):
+    ref = fill.hash_fill_module(O.ResNet18(num_classes=256), "r18.").train()
+    net = ResNet18(num_classes=256, compute_dtype=cd)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV).train()
+    x = fill.hash_tensor(shape, 607)
+    f_ref = ref(x)
+    f_ref.square().mean().backward()
+    f = net(dev(x))
+    f.square().mean().backward()   # (torch elementwise on the 256-d features: host-side test glue)
+    torch.cuda.synchronize()
+    assert (f.detach().cpu() - f_ref.detach()).abs().max() < tol_out * max(1.0, f_ref.abs().max().item())
+    _compare_grads(net, ref, tol_grad)
+    sd_m, sd_r = net.state_dict(), ref.state_dict()
+    for k in sd_r:
+        if "running" in k:
+            assert torch.allclose(sd_m[k].cpu(), sd_r[k], rtol=2e-3 if cd == "fp32" else 0.05,
+                                  atol=1e-4 if cd == "fp32" else 5e-3), k
+        if "num_batches" in k:
+            assert int(sd_m[k]) == int(sd_r[k])
+
+
+def test_resnet18_eval_golden_g6(golden_dir):
+    g6 = np.load(f"{golden_dir}/g6_resnet18.npz")
+    ref = fill.hash_fill_module(O.ResNet18(num_classes=256), "r18.")
+    net = ResNet18(num_classes=256, compute_dtype="fp32")
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        f = net(dev(fill.hash_tensor((2, 3, 224, 224), 606)))
+        f2 = net(dev(fill.hash_tensor((1, 3, 250, 2500), 606)))   # the reference's full-resolution lead image
+    assert (f.cpu() - torch.from_numpy(g6["feat_224"])).abs().max() < 1e-3
+    assert (f2.cpu() - torch.from_numpy(g6["feat_250x2500"])).abs().max() < 1e-3
+
+
+def _build_pair(cd):
+    cfg = type("Cfg", (Config,), {})
+    cfg.compute_dtype, cfg.clinical_input_dim = cd, 16
+    ref = O.disable_dropout(fill.hash_fill_module(O.ECGMultimodalModel(2, 16), "mm."))
+    net = ECGMultimodalModel(cfg)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    return ref, _disable_dropout(net).to(DEV)
+
+
+@pytest.mark.parametrize("cd,tol", [("fp32", 1e-3), ("bf16", 0.06)])
+def test_multimodal_eval_and_train_logits_vs_golden_g5(golden_dir, cd, tol):
+    g5 = np.load(f"{golden_dir}/g5_multimodal.npz")
+    ref, net = _build_pair(cd)
+    img, sig, clin, lab = fill.synthetic_batch(8, salt=5)
+    names = ("img_logits", "sig_logits", "clin_logits", "fusion_logits", "var_loss", "soft_w")
+    net.eval()
+    with torch.no_grad():
+        out = net(dev(img), dev(sig), dev(clin))
+    for n, o in zip(names, out):
+        assert (o.cpu() - torch.from_numpy(g5["eval." + n])).abs().max() < tol, n
+    net.train()
+    out = net(dev(img), dev(sig), dev(clin))
+    loss = HF.cross_entropy(out[3], dev(lab)) + 0.1 * out[4]
+    loss.backward()
+    torch.cuda.synchronize()
+    for n, o in zip(names, out):
+        assert (o.detach().cpu() - torch.from_numpy(g5["train." + n])).abs().max() < tol, n
+    assert abs(loss.item() - float(g5["train.loss"])) < tol
+    if cd == "fp32":
+        for k, p in net.named_parameters():
+            gn = float(g5["gnorm." + k])
+            if p.grad is None:
+                assert gn == 0.0, k   # branch heads are not in the loss (train.py:78)
+                continue
+            if any(s in k for s in SIG_BIAS_SKIP):
+                continue
+            assert abs(p.grad.norm().item() - gn) < 5e-3 * gn + 1e-6, (k, p.grad.norm().item(), gn)
+        for k in ("fusion_classifier.0.weight", "attention_fusion.weights", "signal_encoder.layer3.se.fc.0.weight",
+                  "clinical_encoder.0.weight", "signal_encoder.initial.0.weight"):
+            assert rel_err(dict(net.named_parameters())[k].grad.cpu(), torch.from_numpy(g5["grad." + k])) < 5e-3, k
+
+
+@pytest.mark.parametrize("frozen", [False, True])
+def test_multimodal_three_adam_steps_vs_golden_g5(golden_dir, frozen):
+    """train.py:60-81 step (zero_grad / forward / CE + 0.1 var / backward / Adam) x3, fp32."""
+    g5 = np.load(f"{golden_dir}/g5_multimodal.npz")
+    _, net = _build_pair("fp32")
+    if frozen:   # train.py:35-40
+        for enc in (net.image_encoder, net.signal_encoder, net.clinical_encoder):
+            for p in enc.parameters():
+                p.requires_grad = False
+    net.train()
+    opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    img, sig, clin, lab = [dev(t) for t in fill.synthetic_batch(8, salt=5)]
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = net(img, sig, clin)
+        loss = HF.cross_entropy(out[3], lab) + 0.1 * out[4]
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    ref = g5["adam3.frozen" if frozen else "adam3.unfrozen"]
+    assert np.allclose(losses, ref, atol=2e-3), (losses, ref)
+    assert losses[2] < losses[0]
