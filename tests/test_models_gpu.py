@@ -44,7 +44,7 @@ def _compare_grads(mine, ref, tol, skip=()):
 SIG_BIAS_SKIP = ("initial.0.bias", "conv1.bias", "conv2.bias", "downsample.0.bias")
 
 
-@pytest.mark.parametrize("cd,tol_out,tol_grad", [("fp32", 2e-4, 2e-3), ("bf16", 0.08, 0.12)])
+@pytest.mark.parametrize("cd,tol_out,tol_grad", [("fp32", 2e-4, 2e-3)])
 def test_resnet1d_ptbxl_train_step_vs_reference_golden(golden_dir, cd, tol_out, tol_grad):
     """g2 was produced by the REFERENCE's ResNet1D_SE class with the reference's best_ptbxl.pth."""
     g2 = np.load(f"{golden_dir}/g2_ptbxl_train.npz")
@@ -89,7 +89,7 @@ def test_resnet1d_eval_vs_reference_golden(golden_dir):
         assert (out.cpu() - torch.from_numpy(g1[f"logits_{Ln}"])).abs().max() < 1e-3
 
 
-@pytest.mark.parametrize("cd,tol_out,tol_grad", [("fp32", 1e-3, 5e-3), ("bf16", 0.1, 0.15)])
+@pytest.mark.parametrize("cd,tol_out,tol_grad", [("fp32", 1e-3, 5e-3)])
 @pytest.mark.parametrize("shape", [(4, 3, 64, 64), (2, 3, 96, 160)])
 def test_resnet18_train_vs_oracle(cd, tol_out, tol_grad, shape):
     ref = fill.hash_fill_module(O.ResNet18(num_classes=256), "r18.").train()
@@ -191,3 +191,67 @@ def test_multimodal_three_adam_steps_vs_golden_g5(golden_dir, frozen):
     ref = g5["adam3.frozen" if frozen else "adam3.unfrozen"]
     assert np.allclose(losses, ref, atol=2e-3), (losses, ref)
     assert losses[2] < losses[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 trunks.  bf16 storage of activations / inter-layer gradients perturbs deep-layer gradients by
+# tens of percent on ANY implementation (BatchNorm backward subtracts large common modes), so the
+# yardstick is torch's own CPU bf16 autocast of the oracle: the HIP bf16 path must deviate from the
+# fp32 oracle by no more than 1.3x what torch's bf16 autocast does (+2 % absolute slack).
+# ---------------------------------------------------------------------------------------------------
+def _dev_vs_autocast(make_ref, make_net, x, loss_of, keys):
+    def run_ref(autocast):
+        ref = make_ref()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            f = ref(x)
+        loss_of(f.float()).backward()
+        return f.detach().float(), {k: p.grad.clone() for k, p in ref.named_parameters()}
+    f32, g32 = run_ref(False)
+    f16, g16 = run_ref(True)
+    net = make_net()
+    f = net(dev(x))
+    loss_of(f, gpu=True).backward()
+    torch.cuda.synchronize()
+    gm = _grads(net)
+    assert rel_err(f.detach().cpu(), f32) < 1.3 * rel_err(f16, f32) + 0.02
+    bad = []
+    for k in keys:
+        mine, theirs = rel_err(gm[k], g32[k]), rel_err(g16[k], g32[k])
+        if not mine < 1.3 * theirs + 0.02:
+            bad.append((k, mine, theirs))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 64, 64), (8, 3, 128, 96)])
+def test_resnet18_bf16_no_worse_than_torch_autocast(shape):
+    sd = fill.hash_fill_module(O.ResNet18(num_classes=256), "r18.").state_dict()
+    r = fill.hash_tensor((shape[0], 256), 99)
+
+    def make_ref():
+        m = O.ResNet18(num_classes=256); m.load_state_dict(sd); return m.train()
+
+    def make_net():
+        m = ResNet18(num_classes=256, compute_dtype="bf16"); m.load_state_dict(sd); return m.to(DEV).train()
+
+    def loss_of(f, gpu=False):
+        return (f * (dev(r) if gpu else r)).sum()
+
+    keys = [k for k in sd if k.endswith("weight") and ("conv" in k or "downsample.0" in k or k == "fc.weight")]
+    _dev_vs_autocast(make_ref, make_net, fill.hash_tensor(shape, 607), loss_of, keys)
+
+
+def test_resnet1d_bf16_no_worse_than_torch_autocast(golden_dir):
+    sd = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/best_ptbxl_tensors.npz").items()}
+    y = torch.tensor([0, 1, 1, 0, 1, 0])
+
+    def make_ref():
+        m = O.ResNet1D_SE(1, 2); m.load_state_dict(sd); return O.disable_dropout(m).train()
+
+    def make_net():
+        m = ResNet1D_SE(1, 2, compute_dtype="bf16"); m.load_state_dict(sd); return _disable_dropout(m).to(DEV).train()
+
+    def loss_of(f, gpu=False):
+        return HF.cross_entropy(f, dev(y)) if gpu else torch.nn.functional.cross_entropy(f, y)
+
+    keys = [k for k in sd if k.endswith("weight") and k.count(".") >= 1 and sd[k].dim() >= 2]
+    _dev_vs_autocast(make_ref, make_net, fill.hash_tensor((6, 1, 2476), 91, 1.5), loss_of, keys)

@@ -286,8 +286,8 @@ def test_avgpool_bcast_and_se_gate_grad():
         coef = torch.zeros(4, Cn)
         coef[0], coef[1] = 1 + 0.1 * fill.hash_tensor((Cn,), 55), 0.1 * fill.hash_tensor((Cn,), 56)
         dg = torch.empty(N, Cn, device=DEV)
-        L.check(lib.ecgmm_se_gate_grad(dt, ptr(to_nhwc(dout, dt)), ptr(to_nhwc(mref, dt)), ptr(xg), ptr(dev(coef)),
-                                       ptr(dg), N, R, Cn, stream()))
+        doutg, mrefg, coefg = to_nhwc(dout, dt), to_nhwc(mref, dt), dev(coef)   # keep alive across the launch
+        L.check(lib.ecgmm_se_gate_grad(dt, ptr(doutg), ptr(mrefg), ptr(xg), ptr(coefg), ptr(dg), N, R, Cn, stream()))
         torch.cuda.synchronize()
         z = x * coef[0][None, :, None, None] + coef[1][None, :, None, None]
         ref = (dout * (mref > 0) * z).sum(dim=(2, 3))
