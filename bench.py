@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/s of the full multimodal training step (forward + backward + Adam,
++ RCCL gradient all-reduce when N > 1) on synthetic ECG batches, bf16 trunks, per-GPU batch 256.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; weak scaling: 256 samples per GPU)
+
+Prints ONE JSON line on rank 0 with the driver's fields plus
+  "roofline":     the dominant kernel class (MFMA implicit-GEMM conv) timed with HIP events on its
+                  launch stream inside the timed region, algorithmic FLOPs / time vs the dense bf16
+                  MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md);
+  "cpu_baseline": the CPU oracle (oracle/ref_models.py, a torch-fp32 restatement of the reference
+                  step) timed on this box's host cores at the reference's CPU-runnable config
+                  (batch 8), rank 0 and N == 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FLOP_PER_SAMPLE = {  # SURVEY 8d / BASELINE.md section 4 (algorithmic, fwd + bwd)
+    "multimodal": 11.7585e9,
+    "image_only": 10.6453e9,
+    "signal12": 1.1607e9,
+}
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_F32_MFMA_TFLOPS = 157.3
+PROF_KINDS = ["conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "stem_fwd", "stem_wgrad"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="multimodal", choices=list(FLOP_PER_SAMPLE))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build(args, device):
+    from ecgmm.config import Config
+    from ecgmm.hip import functional as HF
+    cfg = type("BenchConfig", (Config,), {})
+    cfg.compute_dtype, cfg.clinical_input_dim, cfg.num_classes = args.dtype, 16, 2
+    torch.manual_seed(42)
+    HF.manual_seed(42)
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(42 + int(os.environ.get("RANK", 0)))
+    if args.workload == "multimodal":
+        from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+        model = ECGMultimodalModel(cfg)
+        batch = (torch.randn(B, 3, 224, 224, generator=g).clamp_(-1, 1), torch.randn(B, 5000, generator=g),
+                 torch.randn(B, 16, generator=g))
+
+        def loss_fn(out, y):   # train.py:69-78
+            return HF.cross_entropy(out[3], y) + 0.1 * out[4]
+    elif args.workload == "image_only":
+        from ecgmm.train_image_only import ImageOnlyClassifier
+        model = ImageOnlyClassifier(compute_dtype=args.dtype)
+        batch = (torch.randn(B, 3, 224, 224, generator=g).clamp_(-1, 1),)
+
+        def loss_fn(out, y):
+            return HF.cross_entropy(out, y)
+    else:
+        from ecgmm.signal_model import ResNet1D_SE
+        model = ResNet1D_SE(input_channels=12, num_classes=2, compute_dtype=args.dtype)
+        batch = (torch.randn(B, 12, 5000, generator=g),)
+
+        def loss_fn(out, y):
+            return HF.focal_loss(out, y, 1.0, 2.0)
+    labels = torch.randint(0, 2, (B,), generator=g)
+    model = model.to(device).train()
+    batch = tuple(t.to(device) for t in batch)
+    return model, batch, labels.to(device), loss_fn
+
+
+def cpu_baseline(seconds):
+    """Reference CPU path (BASELINE config 1): oracle train step, batch 8, fp32, all host cores."""
+    from oracle import ref_models as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    model = O.ECGMultimodalModel(2, 16).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    B = 8
+    img, sig, clin = torch.randn(B, 3, 224, 224).clamp_(-1, 1), torch.randn(B, 5000), torch.randn(B, 16)
+    lab = torch.randint(0, 2, (B,))
+
+    def step():
+        opt.zero_grad()
+        O.multimodal_loss(model(img, sig, clin), lab).backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds or n >= 50:
+            break
+    return {"value": round(B * n / el, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of oracle.ECGMultimodalModel (torch {torch.__version__} CPU fp32), batch 8, "
+                      f"3x224x224 + 5000-pt + 16-dim, CE + 0.1 var_loss, Adam"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+
+    from ecgmm.hip import lib as L
+    from ecgmm.optim import FusedAdam
+    from ecgmm.parallel import DataParallel, flatten
+
+    model, batch, labels, loss_fn = build(args, device)
+    flatten(model)
+    ddp = DataParallel(model) if world > 1 else None
+    opt = FusedAdam(model.parameters(), lr=1e-4, grad_scale=1.0 / world)
+
+    def step():
+        opt.zero_grad()
+        if ddp is not None:
+            ddp.prepare_backward()
+        loss = loss_fn(model(*batch), labels)
+        loss.backward()
+        if ddp is not None:
+            ddp.reduce_gradients()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib = L.lib()
+    prof = not args.no_prof
+    fence()
+    if prof:
+        L.check(lib.ecgmm_prof_enable(1), "prof_enable")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    roof = None
+    if prof:
+        nk = len(PROF_KINDS)
+        ms, fl, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
+        rc = lib.ecgmm_prof_collect(nk, ms, fl, cnt)
+        lib.ecgmm_prof_enable(0)
+        kinds = {PROF_KINDS[i]: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i in range(nk)}
+        dom = max(("conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad"), key=lambda k: kinds[k]["ms"])
+        # the implicit-GEMM kernel template (fwd + dgrad instantiations) is one kernel class
+        ig_ms = kinds["conv_igemm_fwd"]["ms"] + kinds["conv_igemm_dgrad"]["ms"]
+        ig_fl = kinds["conv_igemm_fwd"]["flops"] + kinds["conv_igemm_dgrad"]["flops"]
+        ig_n = kinds["conv_igemm_fwd"]["launches"] + kinds["conv_igemm_dgrad"]["launches"]
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        if rc == 0 and ig_ms > 0:
+            ach = ig_fl / (ig_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad)", "achieved": round(ach, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "launches": ig_n, "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
+                    "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),
+                    "by_kind": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                    "launches_per_step": v["launches"] // max(args.steps, 1)} for k, v in kinds.items()},
+                    "slowest_kind": dom}
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    if rank == 0:
+        total = args.batch * world * args.steps
+        value = total / elapsed
+        out = {
+            "metric": "samples/sec fwd+bwd, batch-256 multimodal (img+sig+clin), 1->8 MI355X",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": {"multimodal": "full multimodal (image 3x224x224 + 5000-pt signal + 16-dim clinical), "
+                                                   "fwd+bwd+Adam, encoders unfrozen",
+                                    "image_only": "image-only ResNet18 (train_image_only.py), fwd+bwd+Adam",
+                                    "signal12": "12-lead ResNet1D_SE (train_signal_12_af.py), focal loss, fwd+bwd+Adam"}[args.workload],
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 5)},
+            "mfma_roofline_frac_whole_step": round(value / world * FLOP_PER_SAMPLE[args.workload] /
+                                                   ((PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS) * 1e12), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

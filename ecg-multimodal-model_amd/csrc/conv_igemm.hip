@@ -16,7 +16,7 @@
 // reads of 16 consecutive rows spread over the 64 banks.
 // dtype: bf16 -> v_mfma_f32_16x16x32_bf16; f32 -> 4 x v_mfma_f32_16x16x4_f32 per 16-B fragment pair
 // (exact fp32 fma chain -- the 1e-3 parity path).
-#include "common.h"
+#include "ops.h"
 
 namespace {
 
@@ -295,6 +295,10 @@ int launch_T(const IgemmParams& p, int mode, hipStream_t stream) {
 // rows of the BatchNorm partial-sum buffer a forward launch writes (2 per 128-pixel tile)
 int ecg_conv_stats_rows(long M) { return 2 * ceil_div(M, BM); }
 
+static inline double conv_flops(const ConvGeom& g) {
+  return 2.0 * (double)g.N * g.OH * g.OW * g.Cout * g.R * g.S * g.Cin;
+}
+
 // mode 0: forward (src = x, dst = y); mode 1: dgrad (src = dy, dst = dx; g still describes the FORWARD conv)
 int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst,
                    const float* bias, const void* addend, float* stats, int act, hipStream_t stream) {
@@ -312,7 +316,9 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
   p.M = (int)M;
   const int vec = dtype == ECGMM_BF16 ? 8 : 4;
   if (p.Cs % vec != 0) ECG_FAIL(ECGMM_ERR_SHAPE, "conv: reduction channels %d not a multiple of %d", p.Cs, vec);
-  if (dtype == ECGMM_BF16) return launch_T<bf16_t>(p, mode, stream);
-  if (dtype == ECGMM_F32) return launch_T<float>(p, mode, stream);
-  ECG_FAIL(ECGMM_ERR_DTYPE, "conv: bad dtype %d", dtype);
+  if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "conv: bad dtype %d", dtype);
+  ecg_prof_begin(mode == 0 ? ECG_PROF_IGEMM_FWD : ECG_PROF_IGEMM_DGRAD, conv_flops(g), stream);
+  int rc = dtype == ECGMM_BF16 ? launch_T<bf16_t>(p, mode, stream) : launch_T<float>(p, mode, stream);
+  ecg_prof_end(stream);
+  return rc;
 }

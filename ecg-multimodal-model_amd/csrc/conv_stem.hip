@@ -8,7 +8,7 @@
 // floats of one patch row.  Output is channels-last [N, OH, OW, 64] in the compute dtype.
 // Forward: A = packed weights (rows = out channels), B = patch (cols = pixels).
 // Wgrad:   A = dy^T via transposing LDS reads, B = patch values of 8 consecutive pixels (stride 2).
-#include "common.h"
+#include "ops.h"
 
 __device__ __host__ inline size_t align_up_dev(size_t a) { return (a + 15) & ~(size_t)15; }
 
@@ -410,6 +410,7 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   const int WS = s.KP + (dtype == ECGMM_BF16 ? 8 : 1);
   size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + patch_bytes(s, Cin, R);
   dim3 grid(N * s.tiles_h * s.tiles_w);
+  ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, stream);
   if (dtype == ECGMM_BF16) {
     hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
   } else if (dtype == ECGMM_F32) {
@@ -422,6 +423,7 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   } else {
     ECG_FAIL(ECGMM_ERR_DTYPE, "stem: bad dtype %d", dtype);
   }
+  ecg_prof_end(stream);
   ECG_CHECK_LAUNCH("stem_fwd");
   return 0;
 }
@@ -449,9 +451,11 @@ int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int a
   p.tiles_per_split = ceil_div(total, nsplit);
   const int grid = ceil_div(total, p.tiles_per_split);
   size_t lds = 128 * (size_t)(dtype == ECGMM_BF16 ? 144 : 320) + patch_bytes(s, Cin, R);
+  if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "stem wgrad: bad dtype %d", dtype);
+  ecg_prof_begin(ECG_PROF_STEM_WGRAD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, stream);
   if (dtype == ECGMM_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, p);
-  else if (dtype == ECGMM_F32) hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(256), lds, stream, p);
-  else ECG_FAIL(ECGMM_ERR_DTYPE, "stem wgrad: bad dtype %d", dtype);
+  else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(256), lds, stream, p);
+  ecg_prof_end(stream);
   ECG_CHECK_LAUNCH("stem_wgrad");
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_CO * s.NG * 7, 256)), dim3(256), 0, stream,
                      (const float*)workspace, grad, grid, s.NG, accumulate);

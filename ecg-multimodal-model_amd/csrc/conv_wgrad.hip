@@ -10,7 +10,7 @@
 // the pixel range (split-K).  Partial tiles go to an fp32 slab [split][tap][co][ci] with plain
 // stores; a second kernel sums the splits in a fixed order (bitwise reproducible) and scatters into
 // the OIHW gradient tensor.
-#include "common.h"
+#include "ops.h"
 
 namespace {
 
@@ -240,9 +240,11 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
   p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.OH = g.OH; p.OW = g.OW; p.Cout = g.Cout; p.S = g.S;
   p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w; p.M = (int)M;
   p.steps_per_split = ceil_div(ceil_div(M, kp), ns);
-  if (dtype == ECGMM_BF16) ECG_TRY(launch_wgrad<bf16_t>(g, p, ns, stream));
-  else if (dtype == ECGMM_F32) ECG_TRY(launch_wgrad<float>(g, p, ns, stream));
-  else ECG_FAIL(ECGMM_ERR_DTYPE, "conv wgrad: bad dtype %d", dtype);
+  if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "conv wgrad: bad dtype %d", dtype);
+  ecg_prof_begin(ECG_PROF_WGRAD, 2.0 * (double)M * g.Cout * g.R * g.S * g.Cin, stream);
+  int rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, stream) : launch_wgrad<float>(g, p, ns, stream);
+  ecg_prof_end(stream);
+  ECG_TRY(rc);
   size_t per = (size_t)g.R * g.S * g.Cout * g.Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, stream, (const float*)workspace,
                      grad_oihw, ns, g.R * g.S, g.Cout, g.Cin, accumulate);

@@ -1,0 +1,56 @@
+// Optional in-library kernel timing with HIP events on the launch stream (used by bench.py for the
+// roofline figure).  Disabled by default: when off, the hooks are a single branch.
+#include "ops.h"
+
+namespace {
+constexpr int MAXEV = 8192;
+struct Rec { int kind; double flops; };
+bool g_on = false;
+int g_n = 0;
+hipEvent_t g_start[MAXEV], g_stop[MAXEV];
+bool g_created = false;
+Rec g_rec[MAXEV];
+int g_open = -1;
+}  // namespace
+
+void ecg_prof_begin(int kind, double flops, hipStream_t s) {
+  if (!g_on || g_n >= MAXEV) { g_open = -1; return; }
+  g_open = g_n++;
+  g_rec[g_open].kind = kind;
+  g_rec[g_open].flops = flops;
+  (void)hipEventRecord(g_start[g_open], s);
+}
+void ecg_prof_end(hipStream_t s) {
+  if (!g_on || g_open < 0) return;
+  (void)hipEventRecord(g_stop[g_open], s);
+  g_open = -1;
+}
+
+extern "C" int ecgmm_prof_enable(int on) {
+  if (on && !g_created) {
+    for (int i = 0; i < MAXEV; ++i) {
+      if (hipEventCreate(&g_start[i]) != hipSuccess || hipEventCreate(&g_stop[i]) != hipSuccess)
+        ECG_FAIL(ECGMM_ERR_LAUNCH, "prof: hipEventCreate failed");
+    }
+    g_created = true;
+  }
+  g_on = on != 0;
+  g_n = 0;
+  g_open = -1;
+  return 0;
+}
+
+// Synchronises the recorded events and accumulates per-kind totals; nkinds entries each.
+extern "C" int ecgmm_prof_collect(int nkinds, double* ms, double* flops, int64_t* count) {
+  for (int k = 0; k < nkinds; ++k) { ms[k] = 0; flops[k] = 0; count[k] = 0; }
+  for (int i = 0; i < g_n; ++i) {
+    if (hipEventSynchronize(g_stop[i]) != hipSuccess) ECG_FAIL(ECGMM_ERR_LAUNCH, "prof: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_start[i], g_stop[i]) != hipSuccess) ECG_FAIL(ECGMM_ERR_LAUNCH, "prof: elapsed failed");
+    int k = g_rec[i].kind;
+    if (k >= 0 && k < nkinds) { ms[k] += t; flops[k] += g_rec[i].flops; count[k] += 1; }
+  }
+  int n = g_n;
+  g_n = 0;
+  return n >= MAXEV ? ECGMM_ERR_WORKSPACE : 0;
+}

@@ -202,6 +202,12 @@ int ecgmm_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr
                float weight_decay, int64_t step, float gscale, void* stream);
 int ecgmm_axpby(float a, const float* x, float b, float* y, int64_t n, void* stream);
 
+/* Measurement only (no reference counterpart): HIP-event timing of the conv kernels on their launch
+ * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad.  collect()
+ * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / launches. */
+int ecgmm_prof_enable(int on);
+int ecgmm_prof_collect(int nkinds, double* ms, double* flops, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif
