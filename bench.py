@@ -86,10 +86,25 @@ def build(args, device):
     return model, batch, labels.to(device), loss_fn
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("ECGMM_CPU_CORES")
+    if env:
+        n = int(env)
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(seconds):
     """Reference CPU path (BASELINE config 1): oracle train step, batch 8, fp32, all host cores."""
     from oracle import ref_models as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     model = O.ECGMultimodalModel(2, 16).train()

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define ECG_WAVE 64
+#define ECG_TAIL_ROWS 64  // spare rows every BatchNorm partial-sum buffer carries (see fold_rows)
 
 // ---- error plumbing (thread-local last error, C return codes) -------------------------------
 void ecg_set_error(const char* fmt, ...);

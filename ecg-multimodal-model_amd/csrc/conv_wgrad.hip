@@ -180,17 +180,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 // grad[co][ci][tap] (OIHW flattened) = sum_split slab[split][tap][co][ci]   (fixed order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int RS,
                                     int Cout, int Cin, int accumulate) {
+  // 256 threads = 64 consecutive outputs x 4 split groups (coalesced 256-B rows, 4-way ILP over splits)
+  __shared__ float sh[4][64];
   size_t per = (size_t)RS * Cout * Cin;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= per) return;
-  int ci = (int)(i % Cin);
-  size_t r = i / Cin;
-  int co = (int)(r % Cout);
-  int tap = (int)(r / Cout);
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * per + i];
-  size_t o = ((size_t)co * Cin + ci) * RS + tap;
-  grad[o] = accumulate ? grad[o] + s : s;
+  size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < per) {
+    int k = grp;
+    for (; k + 4 < nsplit; k += 8) {
+      s0 += slab[(size_t)k * per + i];
+      s1 += slab[(size_t)(k + 4) * per + i];
+    }
+    if (k < nsplit) s0 += slab[(size_t)k * per + i];
+  }
+  sh[grp][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && i < per) {
+    float s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    int ci = (int)(i % Cin);
+    size_t r = i / Cin;
+    int co = (int)(r % Cout);
+    int tap = (int)(r / Cout);
+    size_t o = ((size_t)co * Cin + ci) * RS + tap;
+    grad[o] = accumulate ? grad[o] + s : s;
+  }
 }
 
 template <typename T>
@@ -246,7 +260,7 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
   ecg_prof_end(stream);
   ECG_TRY(rc);
   size_t per = (size_t)g.R * g.S * g.Cout * g.Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per, 256)), dim3(256), 0, stream, (const float*)workspace,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(per, 64)), dim3(256), 0, stream, (const float*)workspace,
                      grad_oihw, ns, g.R * g.S, g.Cout, g.Cin, accumulate);
   ECG_CHECK_LAUNCH("wgrad_reduce_kernel");
   return 0;

@@ -59,6 +59,25 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
+// stage 1 of a long partial-row reduction: block (cg, b) sums rows [b*chunk, (b+1)*chunk) of NQ*C columns
+// into out row b (fp32).  1024 threads = 16 row slices x 64 columns.
+__global__ __launch_bounds__(1024) void rows_stage1_kernel(const float* __restrict__ partial, int rows, int width,
+                                                           int chunk, float* __restrict__ out) {
+  __shared__ double sh[16][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  double s = 0.0;
+  if (col < width)
+    for (int r = r0 + slice; r < r1; r += 16) s += (double)partial[(size_t)r * width + col];
+  sh[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice == 0 && col < width) {
+    for (int k = 1; k < 16; ++k) s += sh[k][threadIdx.x];
+    out[(size_t)blockIdx.y * width + col] = (float)s;
+  }
+}
+
 // eval mode: coefficients straight from the running statistics
 __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                                     float eps, float* coef) {
@@ -298,12 +317,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // sum rows of a [rows][C] fp32 partial buffer -> out[C] (conv bias grads, linear bias grads)
-__global__ void rows_sum_kernel(const float* __restrict__ partial, int rows, int C, float* out, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ partial, int rows, int C, float* out,
+                                                        int accumulate) {
+  __shared__ double sh[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (c < C)
+    for (int r = slice; r < rows; r += 16) s += (double)partial[(size_t)r * C + c];
+  sh[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    for (int k = 1; k < 16; ++k) s += sh[k][threadIdx.x];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,12 +579,29 @@ inline bool chunk_ok(int C, int dtype) {
 int ecg_bn_rows(int dtype, long M, int C) {
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
   int rpi = EW_THREADS / (C / vec);
-  return ew_grid(M, rpi * 8);
+  int g = ew_grid(M, rpi * 8);
+  return g > 1024 ? 1024 : g;
+}
+
+// Long partial-row buffers are first folded to ECG_TAIL_ROWS rows written into the buffer's tail
+// (callers size partial buffers for rows + ECG_TAIL_ROWS rows), so the finalize kernels stay short.
+static int fold_rows(const float*& partial, int& rows, int width, hipStream_t stream) {
+  if (rows <= ECG_TAIL_ROWS) return 0;
+  float* tail = const_cast<float*>(partial) + (size_t)rows * width;
+  int chunk = ceil_div(rows, ECG_TAIL_ROWS);
+  int nb = ceil_div(rows, chunk);
+  hipLaunchKernelGGL(rows_stage1_kernel, dim3(ceil_div(width, 64), nb), dim3(1024), 0, stream, partial, rows, width,
+                     chunk, tail);
+  ECG_CHECK_LAUNCH("rows_stage1");
+  partial = tail;
+  rows = nb;
+  return 0;
 }
 
 int ecg_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                     float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef,
                     hipStream_t stream) {
+  ECG_TRY(fold_rows(partial, rows, 2 * C, stream));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, count, gamma,
                      beta, rm, rv, nbt, momentum, eps, coef);
   ECG_CHECK_LAUNCH("bn_finalize");
@@ -602,7 +646,7 @@ int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, con
 
 // full BN backward: reduce -> finalize -> apply.  scratch: partial rows [rows][2][C] + bcoef [3][C]
 size_t ecg_bn_bwd_scratch(int dtype, long M, int C) {
-  return ((size_t)ecg_bn_rows(dtype, M, C) * 2 * C + 3 * C) * sizeof(float);
+  return ((size_t)(ecg_bn_rows(dtype, M, C) + ECG_TAIL_ROWS) * 2 * C + 3 * C) * sizeof(float);
 }
 
 int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
@@ -611,7 +655,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
   int grid = ecg_bn_rows(dtype, M, C);
   float* partial = scratch;
-  float* bcoef = scratch + (size_t)grid * 2 * C;
+  float* bcoef = scratch + (size_t)(grid + ECG_TAIL_ROWS) * 2 * C;
   BnBwdParams p;
   memset(&p, 0, sizeof(p));
   p.dout = dout; p.maskref = maskref; p.gate = gate; p.addc = addc; p.y = y; p.coef = coef; p.M = M; p.C = C;
@@ -620,8 +664,13 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(EW_THREADS), 0, stream, p),
              hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, grid, C, (double)M,
-                     gamma, coef, dgamma, dbeta, bcoef);
+  {
+    const float* pr = partial;
+    int rows = grid;
+    ECG_TRY(fold_rows(pr, rows, 2 * C, stream));
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, pr, rows, C, (double)M,
+                       gamma, coef, dgamma, dbeta, bcoef);
+  }
   ECG_CHECK_LAUNCH("bn_bwd_finalize");
   if (!dy) return 0;
   p.bcoef = bcoef; p.dy = dy; p.dz_out = dz_out;
@@ -630,14 +679,14 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
              hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");
   if (dbias) {
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, partial, grid, C, dbias, 0);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, grid, C, dbias, 0);
     ECG_CHECK_LAUNCH("rows_sum");
   }
   return 0;
 }
 
 int ecg_rows_sum(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, stream, partial, rows, C, out, accumulate);
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, out, accumulate);
   ECG_CHECK_LAUNCH("rows_sum");
   return 0;
 }

@@ -96,6 +96,7 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
   w.p0 = a.take_bytes((size_t)N * r.H2 * r.W2 * 64 * es);
   w.idx0 = a.take<unsigned char>((size_t)N * r.H2 * r.W2 * 64);
   size_t max_rows_c = (size_t)ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7) * 2 * 64;
+  max_rows_c += (size_t)ECG_TAIL_ROWS * 2 * 64;
   for (int i = 0; i < 8; ++i) {
     const BlockCfg& k = r.blk[i];
     FwdWs::B& b = w.b[i];
@@ -119,7 +120,7 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
       b.wdf = b.wdd = b.yd = nullptr;
       b.coefd = nullptr;
     }
-    size_t rows_c = (size_t)ecg_conv_stats_rows((long)N * k.hout * k.wout) * 2 * k.cout;
+    size_t rows_c = (size_t)(ecg_conv_stats_rows((long)N * k.hout * k.wout) + ECG_TAIL_ROWS) * 2 * k.cout;
     if (rows_c > max_rows_c) max_rows_c = rows_c;
   }
   w.pooled = a.take<float>((size_t)N * 512);

@@ -80,6 +80,7 @@ void layout_fwd(const R1D& r, void* base, Fwd1& w) {
   w.p0 = a.take_bytes((size_t)N * r.L2 * 64 * es);
   w.idx0 = a.take<unsigned char>((size_t)N * r.L2 * 64);
   size_t max_rows_c = (size_t)ecg_stem_stats_rows(N, r.d.cin, 1, r.d.L, 1) * 2 * 64;
+  max_rows_c += (size_t)ECG_TAIL_ROWS * 2 * 64;
   for (int i = 0; i < 3; ++i) {
     const Blk1& k = r.blk[i];
     Fwd1::B& b = w.b[i];
@@ -106,7 +107,7 @@ void layout_fwd(const R1D& r, void* base, Fwd1& w) {
       b.wdf = b.wdd = b.yd = nullptr;
       b.coefd = nullptr;
     }
-    size_t rows_c = (size_t)ecg_conv_stats_rows((long)N * k.lout) * 2 * k.cout;
+    size_t rows_c = (size_t)(ecg_conv_stats_rows((long)N * k.lout) + ECG_TAIL_ROWS) * 2 * k.cout;
     if (rows_c > max_rows_c) max_rows_c = rows_c;
   }
   w.pooled = a.take<float>((size_t)N * 256);

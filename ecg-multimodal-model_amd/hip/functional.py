@@ -308,7 +308,7 @@ class BatchNorm1dFn(torch.autograd.Function):
             if B < 2:
                 raise ValueError("Expected more than 1 value per channel when training")  # torch's message
             rows = lib.ecgmm_col_stats_rows(L.F32, B, Cn)
-            partial = torch.empty(rows, 2, Cn, device=dev, dtype=torch.float32)
+            partial = torch.empty(rows + 64, 2, Cn, device=dev, dtype=torch.float32)  # + tail rows (ecgmm.h)
             L.check(lib.ecgmm_col_stats(L.F32, ptr(x), B, Cn, ptr(partial), stream()), "col_stats")
             L.check(lib.ecgmm_bn_finalize(ptr(partial), rows, Cn, float(B), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
                                           ptr(nbt), momentum, eps, ptr(coef), stream()), "bn_finalize")

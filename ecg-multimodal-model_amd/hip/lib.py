@@ -105,6 +105,9 @@ def lib():
                 f"libecgmm_hip.so not found at {LIB_PATH}: the HIP extension is the only compute path "
                 "(no CPU fallback). Build it with `python __graft_entry__.py` or "
                 "`make -C ecg-multimodal-model_amd/csrc`.")
+        # torch ships its own libamdhip64: import it first so that this library binds to the SAME HIP
+        # runtime instance (two runtimes in one process do not see each other's device context)
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)

@@ -128,7 +128,11 @@ int ecgmm_stem_bwd_weight(int dtype, const float* x, const void* dy, float* dw_o
                           size_t ws_bytes, int N, int Cin, int H, int W, int R, void* stream);
 
 /* nn.BatchNorm{1,2}d (train: batch mean / biased var, running update with unbiased var; eval: running
- * stats).  coef = [4][C]: scale, shift, mean, invstd. */
+ * stats).  coef = [4][C]: scale, shift, mean, invstd.
+ * Partial-sum buffers ([rows][2][C] floats, written by conv_fwd / stem_fwd / col_stats) must be
+ * allocated with ECGMM_BN_TAIL_ROWS spare rows after `rows`: bn_finalize folds long buffers into
+ * that tail before the final reduction. */
+#define ECGMM_BN_TAIL_ROWS 64
 int ecgmm_col_stats_rows(int dtype, int64_t M, int C);
 int ecgmm_col_stats(int dtype, const void* x, int64_t M, int C, float* partial, void* stream);
 int ecgmm_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
