@@ -1,0 +1,141 @@
+"""CPU: host-side logic that needs no GPU -- module trees / state-dict compatibility with the oracle
+(== reference key names), config surface, datasets, FusedAdam run planning, and the data-parallel
+wrapper under a world-size-2 gloo group."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from ecgmm.config import Config
+from ecgmm.dataset import ECGMultimodalDataset, get_dataloaders
+from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel, MultimodalModel, ResNet1D_SE
+from ecgmm.signal_model import ECGDataset, FocalLoss
+from ecgmm.train_image_only import ImageOnlyClassifier
+from oracle import ref_models as O
+
+
+def test_state_dict_keys_and_shapes_match_reference_layout(golden_dir):
+    cfg = type("C16", (Config,), {"clinical_input_dim": 16})
+    mine, ref = ECGMultimodalModel(cfg), O.ECGMultimodalModel(2, 16)
+    sm, sr = mine.state_dict(), ref.state_dict()
+    assert list(sm) == list(sr)
+    assert all(sm[k].shape == sr[k].shape and sm[k].dtype == sr[k].dtype for k in sr)
+    assert MultimodalModel is ECGMultimodalModel
+    mine.load_state_dict(sr, strict=True)
+    # the reference's only real checkpoint loads strictly into the signal encoder
+    sd = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/best_ptbxl_tensors.npz").items()}
+    ResNet1D_SE(1, 2).load_state_dict(sd, strict=True)
+    # partial loader semantics of PMB:309-322 (drops classifier.4.*)
+    torch.save(sd, "/tmp/_ptbxl_test.pth")
+    before = mine.signal_encoder.classifier[4].weight.clone()
+    mine.load_pretrained_signal_encoder("/tmp/_ptbxl_test.pth", load_fc=False)
+    assert torch.equal(mine.signal_encoder.classifier[4].weight, before)
+    assert torch.equal(mine.signal_encoder.initial[0].weight, sd["initial.0.weight"])
+    assert list(ImageOnlyClassifier().state_dict())[0] == "image_encoder.conv1.weight"
+    for attr in ("image_encoder", "image_norm", "signal_encoder", "signal_norm", "clinical_encoder", "clinical_norm",
+                 "attention_fusion", "fusion_classifier", "image_classifier", "signal_classifier",
+                 "clinical_classifier", "modal_dim"):
+        assert hasattr(mine, attr)
+    assert mine.get_clinical_feature_dim() == 16 and ECGMultimodalModel(Config).get_clinical_feature_dim() == 24
+
+
+def test_config_surface():
+    for k, v in dict(seed=42, img_height=224, img_width=224, num_classes=2, batch_size=16, num_epochs=30, lr=1e-4,
+                     patience=5, k_outer=5, k_inner=3, checkpoint_dir="./checkpoints").items():
+        assert getattr(Config, k) == v
+    assert Config.device in ("cuda", "cpu") and Config.ecg_csv.endswith("ecg_signals.csv")
+
+
+def test_product_modules_have_no_cpu_path():
+    cfg = type("C16", (Config,), {"clinical_input_dim": 16})
+    m = ECGMultimodalModel(cfg)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 3, 64, 64), torch.zeros(2, 500), torch.zeros(2, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FocalLoss()(torch.zeros(2, 2), torch.zeros(2, dtype=torch.long))
+
+
+def test_datasets():
+    ds = ECGMultimodalDataset(5, Config)
+    img, sig, clin, lab, idx = ds[3]
+    assert img.shape == (3, 224, 224) and img.dtype == torch.float32 and img.abs().max() <= 1
+    assert sig.shape == (5000,) and clin.shape == (24,) and lab.dtype == torch.int64 and idx == 3
+    assert torch.equal(ds[3][1], sig)
+    cfg = type("Small", (Config,), {"synthetic_train_size": 32, "batch_size": 8})
+    tr, va, te = get_dataloaders(cfg)
+    *batch, index = next(iter(tr))
+    assert [t.shape[0] for t in batch] == [8, 8, 8, 8] and len(index) == 8
+    d = ECGDataset(np.ones((3, 7)), [0, 1, 0])
+    assert len(d) == 3 and d[1][0].dtype == torch.float32 and d[1][1].dtype == torch.int64
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from ecgmm.parallel import DataParallel, flatten
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)          # different init per rank: the wrapper must broadcast rank 0's
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    flatten(net)
+    ddp = DataParallel(net, bucket_mb=1e-5)            # tiny buckets: exercise the bucket loop
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]   # contiguous shards
+    ddp.prepare_backward()
+    loss = ((ddp(xs) - ys) ** 2).mean()
+    for p in net.parameters():
+        p.grad.zero_()
+    loss.backward()                                     # plain torch autograd accumulates into the flat views
+    ddp.reduce_gradients()
+    flat_p, flat_g = net._ecg_flat[0].clone(), net._ecg_flat[1].clone() * ddp.grad_scale
+    if rank == 0:
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        with torch.no_grad():
+            for pr, pm in zip(ref.parameters(), net.parameters()):
+                pr.copy_(pm)
+        ((ref(X) - Y) ** 2).mean().backward()
+        gref = torch.cat([(p.grad.reshape(-1)) for p in ref.parameters()])
+        mine = torch.cat([p.grad.reshape(-1) * ddp.grad_scale for p in net.parameters()])
+        out.put((torch.allclose(mine, gref, atol=1e-6), float((mine - gref).abs().max())))
+    gathered = [torch.zeros_like(flat_p) for _ in range(world)]
+    dist.all_gather(gathered, flat_p)
+    if rank == 0:
+        out.put(all(torch.equal(gathered[0], t) for t in gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2_matches_full_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    ok, err = q.get(timeout=10)
+    assert ok, f"averaged shard gradients differ from the full-batch gradient by {err}"
+    assert q.get(timeout=10), "parameters were not identical across ranks after the initial broadcast"
+
+
+def test_fused_adam_run_planning_cpu():
+    """Run merging over the padded flat buffer needs no GPU: only pointer arithmetic."""
+    from ecgmm.optim import FusedAdam
+    from ecgmm.parallel import flatten
+    net = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.Linear(2, 3))   # sizes 6, 2, 6, 3: all need padding
+    flatten(net)
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    opt._build_runs()
+    assert len(opt._runs) == 1 and opt._runs[0]["n"] == 8 + 4 + 8 + 3 and opt._runs_valid()
+    net[0].weight.requires_grad = False
+    opt2 = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    opt2._build_runs()
+    assert len(opt2._runs) == 1 and opt2._runs[0]["params"][0] is net[0].bias

@@ -1,0 +1,95 @@
+"""CPU: the oracle restatement reproduces the committed goldens (g1-g4 were generated from the
+REFERENCE's own classes in the build container by oracle/make_golden.py)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import fill, ref_models as O
+
+
+def _sd(golden_dir):
+    return {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/best_ptbxl_tensors.npz").items()}
+
+
+def test_hash_fill_is_machine_independent():
+    v = fill.hash_uniform(5, 77)
+    assert v.dtype == np.float32 and np.all(np.abs(v) <= 1)
+    assert np.array_equal(v, fill.hash_uniform(5, 77))
+    # frozen values: any change to the hash would silently invalidate every golden
+    assert np.array_equal(fill.hash_uniform(3, 1),
+                          np.array([0.30292809009552, -0.631522536277771, 0.32319724559783936], dtype=np.float32))
+    assert abs(float(fill.hash_uniform(1000, 3).mean())) < 0.1
+
+
+def test_resnet1d_eval_matches_reference_golden(golden_dir):
+    g1 = np.load(f"{golden_dir}/g1_ptbxl_eval.npz")
+    net = O.ResNet1D_SE(1, 2)
+    net.load_state_dict(_sd(golden_dir), strict=True)
+    net.eval()
+    for L in (2476, 5000):
+        with torch.no_grad():
+            out = net(fill.hash_tensor((4, 1, L), 77 + L, 1.5))
+        assert torch.allclose(out, torch.from_numpy(g1[f"logits_{L}"]), atol=1e-5)
+
+
+def test_resnet1d_train_step_matches_reference_golden(golden_dir):
+    g2 = np.load(f"{golden_dir}/g2_ptbxl_train.npz")
+    net = O.disable_dropout(O.ResNet1D_SE(1, 2))
+    net.load_state_dict(_sd(golden_dir), strict=True)
+    net.train()
+    lo = net(fill.hash_tensor((4, 1, 2476), 91, 1.5))
+    loss = F.cross_entropy(lo, torch.tensor([0, 1, 1, 0]))
+    loss.backward()
+    assert torch.allclose(lo.detach(), torch.from_numpy(g2["logits"]), atol=1e-5)
+    assert abs(loss.item() - float(g2["loss"])) < 1e-6
+    g = dict(net.named_parameters())["layer3.conv2.weight"].grad
+    assert torch.allclose(g, torch.from_numpy(g2["grad.layer3.conv2.weight"]), rtol=1e-3, atol=1e-7)
+
+
+def test_focal_loss_known_answers(golden_dir):
+    g4 = np.load(f"{golden_dir}/g4_focal.npz")
+    v = O.FocalLoss()(torch.tensor([[2.0, -1.0], [0.3, 0.1]]), torch.tensor([0, 1]))
+    assert abs(v.item() - 0.12070029228925705) < 1e-7
+    assert abs(v.item() - float(g4["kat"])) < 1e-7
+    v2 = O.FocalLoss(0.25, 2.0)(torch.from_numpy(g4["logits"]), torch.from_numpy(g4["targets"]))
+    assert abs(v2.item() - float(g4["loss_a025"])) < 1e-7
+    v3 = O.FocalLoss(reduce=False)(torch.from_numpy(g4["logits"]), torch.from_numpy(g4["targets"]))
+    assert torch.allclose(v3, torch.from_numpy(g4["loss_unreduced"]), atol=1e-7)
+
+
+def test_sig12_adam_onecycle_trajectory(golden_dir):
+    g3 = np.load(f"{golden_dir}/g3_sig12_steps.npz")
+    net = O.disable_dropout(fill.hash_fill_module(O.ResNet1D_SE(12, 2), "sig12.")).train()
+    x, y = fill.hash_tensor((8, 12, 5000), 555, 1.5), torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, steps_per_epoch=4, epochs=30)
+    crit = O.FocalLoss(1.0, 2.0)
+    for i in range(3):
+        assert abs(opt.param_groups[0]["lr"] - g3["lrs"][i]) < 1e-12
+        assert abs(opt.param_groups[0]["betas"][0] - g3["beta1s"][i]) < 1e-9   # cycle_momentum rewrites beta1
+        opt.zero_grad()
+        loss = crit(net(x), y)
+        loss.backward()
+        opt.step(); sch.step()
+        assert abs(loss.item() - g3["losses"][i]) < 2e-4
+
+
+def test_structure_of_the_resnet18_restatement():
+    r = O.ResNet18()
+    keys = list(r.state_dict())
+    assert len(keys) == 122 and keys[0] == "conv1.weight" and keys[-1] == "fc.bias"
+    assert "layer2.0.downsample.1.num_batches_tracked" in keys and "layer1.0.downsample.0.weight" not in keys
+    assert sum(p.numel() for p in r.parameters()) == 11689512
+    m = O.ECGMultimodalModel(2, 16)
+    assert sum(p.numel() for p in m.parameters()) == 11911975
+    assert sum(p.numel() for p in O.ResNet1D_SE(12, 2).parameters()) == 471390
+
+
+def test_multimodal_oracle_matches_g5(golden_dir):
+    g5 = np.load(f"{golden_dir}/g5_multimodal.npz")
+    model = O.disable_dropout(fill.hash_fill_module(O.ECGMultimodalModel(2, 16), "mm.")).eval()
+    img, sig, clin, lab = fill.synthetic_batch(8, salt=5)
+    with torch.no_grad():
+        out = model(img, sig, clin)
+    assert torch.allclose(out[3], torch.from_numpy(g5["eval.fusion_logits"]), atol=2e-5)
+    assert abs(out[4].item() - float(g5["eval.var_loss"])) < 1e-5
