@@ -35,6 +35,15 @@ template <> struct Mma<float> {
   }
 };
 
+// 16-byte LDS-DMA buffer load (global -> LDS, no VGPR).  The 16-byte form only exists on gfx950; the
+// host pass of hipcc checks builtins against its own target, so the body is device-pass only.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_wave_base, unsigned voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0,
+                                           0);
+#endif
+}
+
 struct IgemmParams {
   const void* src;
   const void* wpk;
@@ -42,7 +51,7 @@ struct IgemmParams {
   const float* bias;
   const void* addend;
   float* stats;  // [2*gridDim.x][2][Cd] partial (sum, sumsq) or null
-  int Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad_h, pad_w;
+  int Nimg, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad_h, pad_w;
   int M;  // destination pixels
   int act;
 };
@@ -69,19 +78,33 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   const T* __restrict__ src = (const T*)p.src;
   const T* __restrict__ wpk = (const T*)p.wpk;
 
-  // ---- per-thread gather bookkeeping: 4 activation rows + NWV weight rows, one 16-B chunk each
-  const int chunk = tid & 7, lrow = tid >> 3;  // lrow 0..31
-  int nb[4], hb[4], wb[4];
-  bool rok[4];
+  // ---- gather bookkeeping.  All global reads are LDS-DMA buffer loads (buffer_load_dwordx4 ... lds):
+  // a 32-bit byte offset from a per-workgroup base (the sample of the tile's first pixel), hardware
+  // zero-fill for anything out of range (padding, ragged tiles, partial channel stages), no VGPR
+  // staging and no ds_write.  One wave-instruction fills 1 KiB = 8 LDS rows x 128 B; the XOR swizzle
+  // is applied on the SOURCE side (lane -> logical chunk), the LDS image stays lane-linear.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int lrow8 = lane >> 3;                    // row within an 8-row DMA piece
+  const int lchunk = (lane & 7) ^ (lrow8 & 7);    // logical 16-B chunk this lane fetches
+  const int HWd = p.Hd * p.Wd;
+  const int n_first = m0 / HWd;
+  const size_t img_elems = (size_t)p.Hs * p.Ws * p.Cs;
+  const size_t left = ((size_t)p.Nimg - n_first) * img_elems * sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(src + (size_t)n_first * img_elems), 0, left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)wpk, 0, (int)((size_t)p.Cd * p.R * p.S * p.Cs * sizeof(T)), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  int nbh[4], hb[4], wb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int pix = m0 + lrow + 32 * i;
-    rok[i] = pix < p.M;
-    int pp = rok[i] ? pix : 0;
-    int n = pp / (p.Hd * p.Wd);
-    int rem = pp - n * (p.Hd * p.Wd);
+    int pix = m0 + wave * 32 + i * 8 + lrow8;
+    bool rok = pix < p.M;
+    int pp = rok ? pix : m0;
+    int n = pp / HWd;
+    int rem = pp - n * HWd;
     int hd = rem / p.Wd, wd = rem - hd * p.Wd;
-    nb[i] = n * p.Hs;
+    nbh[i] = (n - n_first) * p.Hs;
     if (MODE == 0) {
       hb[i] = hd * p.stride - p.pad_h;
       wb[i] = wd * p.stride - p.pad_w;
@@ -89,29 +112,37 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       hb[i] = hd + p.pad_h;
       wb[i] = wd + p.pad_w;
     }
+    if (!rok) hb[i] = MODE == 0 ? -(1 << 28) : (1 << 28);  // every tap of a padding row falls out of range
   }
   const int RS = p.R * p.S;
   const int cpt = (p.Cs + KBE - 1) / KBE;  // stages per tap
   const int nk = RS * cpt;
+  const unsigned pix_bytes = (unsigned)p.Cs * (unsigned)sizeof(T);
+  unsigned wrow[NWV];
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) {
+    int j = n0 + wave * (BN / 4) + i * 8 + lrow8;
+    wrow[i] = j < p.Cd ? (unsigned)j * (unsigned)RS * pix_bytes : OOB;
+  }
 
-  u32x4 va[4], vw[NWV];
-  auto gload = [&](int it) {
-    int tap = it / cpt, cc = it - tap * cpt;
-    int r = tap / p.S, s = tap - r * p.S;
-    int ch = cc * KBE + chunk * VEC;
-    bool chok = ch < p.Cs;
+  int g_r = 0, g_s = 0, g_cc = 0;  // wave-uniform tap / channel-stage counters (stages are issued in order)
+  auto dma = [&](int stage) {
+    unsigned char* sW = smem + stage * STAGE_BYTES;
+    unsigned char* sX = sW + BN * ROWB;
+    const int r = g_r, s = g_s;
+    const int ch = g_cc * KBE + lchunk * VEC;
+    const unsigned chb = ch < p.Cs ? (unsigned)ch * (unsigned)sizeof(T) : OOB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int hs, ws;
-      bool ok = rok[i] && chok;
+      bool ok = true;
       if (MODE == 0) {
         hs = hb[i] + r;
         ws = wb[i] + s;
       } else {
         int th = hb[i] - r, tw = wb[i] - s;
-        ok = ok && th >= 0 && tw >= 0;
         if (ST == 2) {
-          ok = ok && ((th | tw) & 1) == 0;
+          ok = ((th | tw) & 1) == 0;
           hs = th >> 1;
           ws = tw >> 1;
         } else {
@@ -120,32 +151,20 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
         }
       }
       ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        size_t off = ((size_t)(nb[i] + hs) * p.Ws + ws) * p.Cs + ch;
-        v = *reinterpret_cast<const u32x4*>(src + off);
-      }
-      va[i] = v;
+      unsigned off = (unsigned)((nbh[i] + hs) * p.Ws + ws) * pix_bytes + chb;
+      dma16(rs_src, sX + (wv * 4 + i) * 1024, (ok && chb != OOB) ? off : OOB);
     }
+    const unsigned tapb = (unsigned)(r * p.S + s) * pix_bytes + chb;
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) {
-      int j = n0 + lrow + 32 * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (j < p.Cd && chok) {
-        size_t off = ((size_t)j * RS + tap) * p.Cs + ch;
-        v = *reinterpret_cast<const u32x4*>(wpk + off);
+    for (int i = 0; i < NWV; ++i)
+      dma16(rs_w, sW + (wv * NWV + i) * 1024, (wrow[i] != OOB && chb != OOB) ? wrow[i] + tapb : OOB);
+    if (++g_cc == cpt) {
+      g_cc = 0;
+      if (++g_s == p.S) {
+        g_s = 0;
+        ++g_r;
       }
-      vw[i] = v;
     }
-  };
-  const int pch = (chunk ^ (lrow & 7)) << 4;  // swizzled 16-B chunk offset (row & 7 == lrow & 7)
-  auto lstore = [&](int stage) {
-    unsigned char* sW = smem + stage * STAGE_BYTES;
-    unsigned char* sX = sW + BN * ROWB;
-#pragma unroll
-    for (int i = 0; i < NWV; ++i) *reinterpret_cast<u32x4*>(sW + (lrow + 32 * i) * ROWB + pch) = vw[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sX + (lrow + 32 * i) * ROWB + pch) = va[i];
   };
 
   f32x4 acc[TC][TP];
@@ -179,14 +198,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  dma(0);
+  __syncthreads();  // (drains vmcnt: the LDS-DMA of stage 0 has landed for every wave)
   for (int it = 0; it < nk; ++it) {
-    const bool more = it + 1 < nk;
-    if (more) gload(it + 1);
+    if (it + 1 < nk) dma((it + 1) & 1);  // that buffer was last read in iteration it-1, fenced by its barrier
     compute(it & 1);
-    if (more) lstore((it + 1) & 1);
     __syncthreads();
   }
 
@@ -305,7 +321,7 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.src = src; p.wpk = wpk; p.dst = dst; p.bias = bias; p.addend = addend; p.stats = stats; p.act = act;
-  p.R = g.R; p.S = g.S; p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+  p.Nimg = g.N; p.R = g.R; p.S = g.S; p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
   if (mode == 0) {
     p.Hs = g.H; p.Ws = g.W; p.Cs = g.Cin; p.Hd = g.OH; p.Wd = g.OW; p.Cd = g.Cout;
   } else {

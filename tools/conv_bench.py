@@ -1,0 +1,63 @@
+"""Micro-benchmark of the conv kernels on the ResNet18 / ResNet1D_SE layer shapes (B=256 by default).
+Usage: python tools/conv_bench.py [--batch 256] [--reps 10] [--only fwd,dgrad,wgrad] [--layers l1,l2,...]"""
+import argparse, ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ecgmm.hip import lib as L
+from ecgmm.hip.functional import ptr, stream
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--only", default="fwd,dgrad,wgrad")
+ap.add_argument("--layers", default="")
+ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+B, dt = a.batch, (L.BF16 if a.dtype == "bf16" else L.F32)
+tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
+SHAPES = [  # name, H, W, Cin, Cout, R, S, stride, ph, pw
+    ("l1.3x3", 56, 56, 64, 64, 3, 3, 1, 1, 1), ("l2.3x3s2", 56, 56, 64, 128, 3, 3, 2, 1, 1),
+    ("l2.3x3", 28, 28, 128, 128, 3, 3, 1, 1, 1), ("l2.ds", 56, 56, 64, 128, 1, 1, 2, 0, 0),
+    ("l3.3x3s2", 28, 28, 128, 256, 3, 3, 2, 1, 1), ("l3.3x3", 14, 14, 256, 256, 3, 3, 1, 1, 1),
+    ("l4.3x3s2", 14, 14, 256, 512, 3, 3, 2, 1, 1), ("l4.3x3", 7, 7, 512, 512, 3, 3, 1, 1, 1),
+    ("s1.k3", 1, 1250, 64, 64, 1, 3, 1, 0, 1), ("s2.k3s2", 1, 1250, 64, 128, 1, 3, 2, 0, 1),
+    ("s2.k3", 1, 625, 128, 128, 1, 3, 1, 0, 1), ("s3.k3", 1, 313, 256, 256, 1, 3, 1, 0, 1),
+]
+lib = L.lib()
+dev = torch.device("cuda:0")
+sel = set(a.layers.split(",")) if a.layers else None
+tot = {}
+for name, H, W, Cin, Cout, R, S, st, ph, pw in SHAPES:
+    if sel and name not in sel:
+        continue
+    d = L.ConvDesc(B, H, W, Cin, Cout, R, S, st, ph, pw)
+    OH, OW = (H + 2 * ph - R) // st + 1, (W + 2 * pw - S) // st + 1
+    x = torch.randn(B * H * W * Cin, device=dev).to(tdt)
+    dy = torch.randn(B * OH * OW * Cout, device=dev).to(tdt)
+    w = (torch.randn(Cout * Cin * R * S, device=dev) * 0.05).to(tdt)
+    y = torch.empty_like(dy); dx = torch.empty_like(x)
+    dw = torch.empty(Cout * Cin * R * S, device=dev)
+    rows = lib.ecgmm_conv_stats_rows(B * OH * OW)
+    stats = torch.empty((rows + 64) * 2 * Cout, device=dev)
+    nb = lib.ecgmm_conv_bwd_weight_workspace(dt, C.byref(d))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    flops = 2.0 * B * OH * OW * Cout * R * S * Cin
+    runs = {
+        "fwd": lambda: lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(stats), 0, stream()),
+        "dgrad": lambda: lib.ecgmm_conv_bwd_data(dt, C.byref(d), ptr(dy), ptr(w), None, ptr(dx), stream()),
+        "wgrad": lambda: lib.ecgmm_conv_bwd_weight(dt, C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), nb, stream()),
+    }
+    line = f"{name:10s}"
+    for k in a.only.split(","):
+        for _ in range(2):
+            L.check(runs[k]())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            runs[k]()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.reps
+        tot[k] = tot.get(k, 0) + us
+        line += f"  {k} {us:7.1f} us {flops / us / 1e6:6.0f} TF"
+    print(line, flush=True)
+print("sum us:", {k: round(v, 1) for k, v in tot.items()})
