@@ -228,9 +228,23 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] + bv[j];
       if (addend && pok) {
+        const T* ap = addend + (size_t)pix * p.Cd + ch0;
+        if (vec_ok && ch0 + 3 < p.Cd) {  // 4 consecutive channels: one 8-B (bf16) / 16-B (f32) load
+          if (sizeof(T) == 2) {
+            uint2 pk = *reinterpret_cast<const uint2*>(ap);
+            v[0] += __uint_as_float(pk.x << 16);
+            v[1] += __uint_as_float(pk.x & 0xFFFF0000u);
+            v[2] += __uint_as_float(pk.y << 16);
+            v[3] += __uint_as_float(pk.y & 0xFFFF0000u);
+          } else {
+            float4 f4 = *reinterpret_cast<const float4*>(ap);
+            v[0] += f4.x; v[1] += f4.y; v[2] += f4.z; v[3] += f4.w;
+          }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ch0 + j < p.Cd) v[j] += Elem<T>::ld(addend + (size_t)pix * p.Cd + ch0 + j);
+          for (int j = 0; j < 4; ++j)
+            if (ch0 + j < p.Cd) v[j] += Elem<T>::ld(ap + j);
+        }
       }
       if (p.act == 1) {
 #pragma unroll

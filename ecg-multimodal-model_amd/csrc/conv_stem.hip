@@ -327,18 +327,29 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
 }
 
 // grad[co][c][r][s] = sum_split slab[split][co][(c*R + r)*8 + s]   (s < 7)
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int NG,
-                                         int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int total = STEM_CO * NG * 7;
-  if (i >= total) return;
-  int s = i % 7;
-  int t = i / 7;
-  int G = t % NG, co = t / NG;
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                float* __restrict__ grad, int nsplit, int NG,
+                                                                int accumulate) {
+  // 256 threads = 16 outputs x 16 split slices
+  __shared__ float sh[16][17];
+  const int oi = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + oi;
+  const int total = STEM_CO * NG * 7;
   const int NK = NG * 8;
   float acc = 0.f;
-  for (int k = 0; k < nsplit; ++k) acc += slab[((size_t)k * STEM_CO + co) * NK + G * 8 + s];
-  grad[i] = accumulate ? grad[i] + acc : acc;
+  if (i < total) {
+    int s = i % 7;
+    int t = i / 7;
+    int G = t % NG, co = t / NG;
+    for (int k = sl; k < nsplit; k += 16) acc += slab[((size_t)k * STEM_CO + co) * NK + G * 8 + s];
+  }
+  sh[sl][oi] = acc;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float v = 0.f;
+    for (int k = 0; k < 16; ++k) v += sh[k][oi];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
 }
 
 // OIHW fp32 [64][Cin][R][7] -> [64][KP] T with k = (c*R + r)*8 + s
@@ -457,7 +468,7 @@ int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int a
   else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(256), lds, stream, p);
   ecg_prof_end(stream);
   ECG_CHECK_LAUNCH("stem_wgrad");
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_CO * s.NG * 7, 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_CO * s.NG * 7, 16)), dim3(256), 0, stream,
                      (const float*)workspace, grad, grid, s.NG, accumulate);
   ECG_CHECK_LAUNCH("stem_wgrad_reduce");
   return 0;

@@ -433,22 +433,55 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_relu_bwd_kernel(const T* _
 // ------------------------------------------------------------------------------------------------
 // global average pool over the rows of each sample: [N][R][C] T -> [N][C] f32; and its broadcast
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, int R,
-                                                             int C, const float* __restrict__ coef) {
-  // one block per (sample, 64-channel group); 4 row slices x 64 channels
-  __shared__ float sh[4][64];
-  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < C)
-    for (int r = slice; r < R; r += 4) s += Elem<T>::ld(x + ((size_t)n * R + r) * C + c);
-  sh[slice][threadIdx.x & 63] = s;
+// One block per sample; thread = (16-B channel chunk, row slice); LDS fold over the slices.
+// SEGATE = false: out[n][c] = mean_r x[n,r,c] (optionally through the per-channel affine coef)
+// SEGATE = true : out[n][c] = sum_r [maskref > 0] * dout * (y * scale + shift)   (x = dout)
+template <typename T, bool SEGATE>
+__global__ __launch_bounds__(EW_THREADS) void sample_reduce_kernel(const T* __restrict__ x,
+                                                                   const T* __restrict__ maskref,
+                                                                   const T* __restrict__ y,
+                                                                   const float* __restrict__ coef,
+                                                                   float* __restrict__ out, int R, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float sh[EW_THREADS][VEC + 1];
+  const int cpr = C / VEC, nsl = EW_THREADS / cpr;
+  const int chunk = threadIdx.x % cpr, slice = threadIdx.x / cpr;
+  const int n = blockIdx.x, c0 = chunk * VEC;
+  float acc[VEC], sc[VEC], sf[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    acc[j] = 0.f;
+    sc[j] = (SEGATE || coef) ? coef[c0 + j] : 1.f;
+    sf[j] = (SEGATE || coef) ? coef[C + c0 + j] : 0.f;
+  }
+  for (int r = slice; r < R; r += nsl) {
+    const size_t o = ((size_t)n * R + r) * C + c0;
+    float f[VEC];
+    unpack16<T>(ld16(x + o), f);
+    if (SEGATE) {
+      float m[VEC], v[VEC];
+      unpack16<T>(ld16(maskref + o), m);
+      unpack16<T>(ld16(y + o), v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (m[j] > 0.f) acc[j] += f[j] * (v[j] * sc[j] + sf[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sh[threadIdx.x][j] = acc[j];
   __syncthreads();
-  if (slice == 0 && c < C) {
-    s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-    float m = s / (float)R;
-    if (coef) m = m * coef[c] + coef[C + c];  // mean of an affine map = affine map of the mean
-    out[(size_t)n * C + c] = m;
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    const int ck = c / VEC, j = c % VEC;
+    float s_ = 0.f;
+    for (int k = 0; k < nsl; ++k) s_ += sh[k * cpr + ck][j];
+    if (!SEGATE) {
+      s_ /= (float)R;
+      if (coef) s_ = s_ * coef[c] + coef[C + c];  // mean of an affine map = affine map of the mean
+    }
+    out[(size_t)n * C + c] = s_;
   }
 }
 
@@ -460,31 +493,6 @@ __global__ void bcast_rows_kernel(const float* __restrict__ v, T* __restrict__ o
     long n = i / ((long)R * C);
     Elem<T>::st(out + i, v[n * C + c] * scale);
   }
-}
-
-// per-sample row reduction of dpre*z for the SE gate gradient:
-// dg[n][c] = sum_r [maskref>0] * dout[n,r,c] * (y[n,r,c]*scale[c] + shift[c])
-template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void se_gate_grad_kernel(const T* __restrict__ dout,
-                                                                  const T* __restrict__ maskref,
-                                                                  const T* __restrict__ y,
-                                                                  const float* __restrict__ coef,
-                                                                  float* __restrict__ dg, int R, int C) {
-  __shared__ float sh[4][64];
-  const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < C) {
-    float sc = coef[c], sf = coef[C + c];
-    for (int r = slice; r < R; r += 4) {
-      size_t o = ((size_t)n * R + r) * C + c;
-      float d = Elem<T>::ld(dout + o);
-      if (Elem<T>::ld(maskref + o) > 0.f) s += d * (Elem<T>::ld(y + o) * sc + sf);
-    }
-  }
-  sh[slice][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (slice == 0 && c < C)
-    dg[(size_t)n * C + c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -724,10 +732,12 @@ int ecg_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const un
 }
 
 int ecg_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, hipStream_t stream) {
-  dim3 grid(N, ceil_div(C, 64));
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "avgpool: C=%d unsupported", C);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, R, C, coef),
-             hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, R, C, coef),
+             hipLaunchKernelGGL((sample_reduce_kernel<bf16_t, false>), dim3(N), dim3(EW_THREADS), 0, stream,
+                                (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, coef, out, R, C),
+             hipLaunchKernelGGL((sample_reduce_kernel<float, false>), dim3(N), dim3(EW_THREADS), 0, stream,
+                                (const float*)x, (const float*)nullptr, (const float*)nullptr, coef, out, R, C),
              "avgpool");
   ECG_CHECK_LAUNCH("avgpool");
   return 0;
@@ -748,12 +758,12 @@ int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, fl
 
 int ecg_se_gate_grad(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, float* dg,
                      int N, int R, int C, hipStream_t stream) {
-  dim3 grid(N, ceil_div(C, 64));
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "se_gate_grad: C=%d unsupported", C);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(se_gate_grad_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)dout,
-                                (const bf16_t*)maskref, (const bf16_t*)y, coef, dg, R, C),
-             hipLaunchKernelGGL(se_gate_grad_kernel<float>, grid, dim3(256), 0, stream, (const float*)dout,
-                                (const float*)maskref, (const float*)y, coef, dg, R, C),
+             hipLaunchKernelGGL((sample_reduce_kernel<bf16_t, true>), dim3(N), dim3(EW_THREADS), 0, stream,
+                                (const bf16_t*)dout, (const bf16_t*)maskref, (const bf16_t*)y, coef, dg, R, C),
+             hipLaunchKernelGGL((sample_reduce_kernel<float, true>), dim3(N), dim3(EW_THREADS), 0, stream,
+                                (const float*)dout, (const float*)maskref, (const float*)y, coef, dg, R, C),
              "se_gate_grad");
   ECG_CHECK_LAUNCH("se_gate_grad");
   return 0;
