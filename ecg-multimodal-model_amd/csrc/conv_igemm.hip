@@ -86,7 +86,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int lrow8 = lane >> 3;                    // row within an 8-row DMA piece
   const int lchunk = (lane & 7) ^ (lrow8 & 7);    // logical 16-B chunk this lane fetches
-  const int HWd = p.Hd * p.Wd;
+  // Stride-2 dgrad runs one grid slice (blockIdx.z) per output-pixel parity class (h&1, w&1): inside a
+  // class every pixel sees the same subset of filter taps (r = r0, r0+2, ...), so no MFMA work is spent
+  // on taps that fall between the strided samples.  Pixels are enumerated over the class sub-lattice.
+  constexpr bool PAR = (MODE == 1 && ST == 2);
+  constexpr int TSTEP = PAR ? 2 : 1;
+  int ph = 0, pw = 0, Hc = p.Hd, Wc = p.Wd, r0 = 0, s0 = 0, Rc = p.R, Sc = p.S, Mc = p.M;
+  if (PAR) {
+    ph = blockIdx.z >> 1;
+    pw = blockIdx.z & 1;
+    Hc = (p.Hd - ph + 1) >> 1;
+    Wc = (p.Wd - pw + 1) >> 1;
+    r0 = (ph + p.pad_h) & 1;
+    s0 = (pw + p.pad_w) & 1;
+    Rc = p.R > r0 ? (p.R - r0 + 1) >> 1 : 0;
+    Sc = p.S > s0 ? (p.S - s0 + 1) >> 1 : 0;
+    Mc = p.Nimg * Hc * Wc;
+    if (m0 >= Mc) return;  // block-uniform
+  }
+  const int HWd = Hc * Wc;
   const int n_first = m0 / HWd;
   const size_t img_elems = (size_t)p.Hs * p.Ws * p.Cs;
   const size_t left = ((size_t)p.Nimg - n_first) * img_elems * sizeof(T);
@@ -99,11 +117,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int pix = m0 + wave * 32 + i * 8 + lrow8;
-    bool rok = pix < p.M;
+    bool rok = pix < Mc;
     int pp = rok ? pix : m0;
     int n = pp / HWd;
     int rem = pp - n * HWd;
-    int hd = rem / p.Wd, wd = rem - hd * p.Wd;
+    int hd = rem / Wc, wd = rem - hd * Wc;
+    if (PAR) {
+      hd = hd * 2 + ph;
+      wd = wd * 2 + pw;
+    }
     nbh[i] = (n - n_first) * p.Hs;
     if (MODE == 0) {
       hb[i] = hd * p.stride - p.pad_h;
@@ -116,7 +138,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   }
   const int RS = p.R * p.S;
   const int cpt = (p.Cs + KBE - 1) / KBE;  // stages per tap
-  const int nk = RS * cpt;
+  const int nk = Rc * Sc * cpt;
   const unsigned pix_bytes = (unsigned)p.Cs * (unsigned)sizeof(T);
   unsigned wrow[NWV];
 #pragma unroll
@@ -129,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   auto dma = [&](int stage) {
     unsigned char* sW = smem + stage * STAGE_BYTES;
     unsigned char* sX = sW + BN * ROWB;
-    const int r = g_r, s = g_s;
+    const int r = r0 + g_r * TSTEP, s = s0 + g_s * TSTEP;
     const int ch = g_cc * KBE + lchunk * VEC;
     const unsigned chb = ch < p.Cs ? (unsigned)ch * (unsigned)sizeof(T) : OOB;
 #pragma unroll
@@ -141,8 +163,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
         ws = wb[i] + s;
       } else {
         int th = hb[i] - r, tw = wb[i] - s;
-        if (ST == 2) {
-          ok = ((th | tw) & 1) == 0;
+        if (ST == 2) {  // (th, tw are even by construction of the parity class)
           hs = th >> 1;
           ws = tw >> 1;
         } else {
@@ -160,7 +181,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       dma16(rs_w, sW + (wv * NWV + i) * 1024, (wrow[i] != OOB && chb != OOB) ? wrow[i] + tapb : OOB);
     if (++g_cc == cpt) {
       g_cc = 0;
-      if (++g_s == p.S) {
+      if (++g_s == Sc) {
         g_s = 0;
         ++g_r;
       }
@@ -198,8 +219,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     }
   };
 
-  dma(0);
-  __syncthreads();  // (drains vmcnt: the LDS-DMA of stage 0 has landed for every wave)
+  if (nk > 0) {
+    dma(0);
+    __syncthreads();  // (drains vmcnt: the LDS-DMA of stage 0 has landed for every wave)
+  }
   for (int it = 0; it < nk; ++it) {
     if (it + 1 < nk) dma((it + 1) & 1);  // that buffer was last read in iteration it-1, fenced by its barrier
     compute(it & 1);
@@ -222,8 +245,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
-      const int pix = m0 + wp * 64 + b * 16 + fr;
-      const bool pok = pix < p.M;
+      int pix = m0 + wp * 64 + b * 16 + fr;
+      const bool pok = pix < Mc;
+      if (PAR) {  // class-local index -> destination pixel
+        int pp = pok ? pix : m0;
+        int n = pp / HWd;
+        int rem = pp - n * HWd;
+        int h2 = rem / Wc, w2 = rem - h2 * Wc;
+        pix = (n * p.Hd + h2 * 2 + ph) * p.Wd + w2 * 2 + pw;
+      }
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] + bv[j];
@@ -299,6 +329,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
 template <typename T, int BN, int MODE, int ST>
 int launch_one(const IgemmParams& p, hipStream_t stream) {
   dim3 grid(ceil_div(p.M, BM), ceil_div(p.Cd, BN));
+  if (MODE == 1 && ST == 2) {  // 4 parity classes; x sized for the largest one
+    long mc = (long)p.Nimg * ((p.Hd + 1) / 2) * ((p.Wd + 1) / 2);
+    grid = dim3(ceil_div(mc, BM), ceil_div(p.Cd, BN), 4);
+  }
   size_t lds = 2 * (size_t)(BN + BM) * ROWB;
   static bool attr_set = false;
   if (!attr_set) {
