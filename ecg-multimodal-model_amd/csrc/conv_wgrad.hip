@@ -18,31 +18,49 @@ struct WgradParams {
   const void* x;
   const void* dy;
   float* slab;
-  int H, W, Cin, OH, OW, Cout, S, stride, pad_h, pad_w;
+  int N, H, W, Cin, OH, OW, Cout, S, stride, pad_h, pad_w;
   int M;
   int steps_per_split;
+  unsigned mul_hw, sh_hw, mul_w, sh_w;  // exact division by OH*OW and OW for x < 2^31 (see magic_div)
 };
 
+// 16-byte LDS-DMA buffer load (device pass only: the host pass checks builtins against its own target)
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_wave_base, unsigned voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0,
+                                           0);
+#endif
+}
+
+// Every tile is KP pixel rows x 64 channels = 4 KiB, filled by ONE 1-KiB LDS-DMA piece per wave; the
+// XOR swizzle of the 16-B chunk index (applied on the source side) makes the fragment reads spread
+// over the banks: bf16 transposing reads touch rows {q, 8+q} per 32-lane half, f32 reads rows {k, k+1}.
 template <typename T> struct WgCfg;
 template <> struct WgCfg<bf16_t> {
-  static constexpr int KP = 32;          // pixels per K step
-  static constexpr int ROWSTRIDE = 144;  // 64 ch * 2 B + 16 B pad
-  static constexpr int CH = 8;           // 16-B chunks per row
+  static constexpr int KP = 32;    // pixels per K step
+  static constexpr int RB = 128;   // row bytes (64 ch)
+  static constexpr int CPR = 8;    // 16-B chunks per row
+  static constexpr int RPP = 8;    // rows per DMA piece
+  static __device__ __forceinline__ int swz(int row) { return ((row & 3) ^ ((row >> 3) & 1)) << 1; }
 };
 template <> struct WgCfg<float> {
   static constexpr int KP = 16;
-  static constexpr int ROWSTRIDE = 320;  // 64 ch * 4 B + 64 B pad (k-groups land on disjoint banks)
-  static constexpr int CH = 16;
+  static constexpr int RB = 256;
+  static constexpr int CPR = 16;
+  static constexpr int RPP = 4;
+  static __device__ __forceinline__ int swz(int row) { return (row & 1) << 2; }
 };
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   using C = WgCfg<T>;
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int TILE_BYTES = C::KP * C::ROWSTRIDE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(1 + NT) * TILE_BYTES];
+  constexpr int TILE_BYTES = C::KP * C::RB;  // 4096
+  constexpr int STAGE_BYTES = (1 + NT) * TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][1 + NT tiles]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int wco = wave & 1, wci = wave >> 1;
   const int ci_tiles = (p.Cin + 63) / 64;
   const int co0 = (blockIdx.x / ci_tiles) * 64, ci0 = (blockIdx.x % ci_tiles) * 64;
@@ -50,7 +68,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const T* __restrict__ x = (const T*)p.x;
   const T* __restrict__ dy = (const T*)p.dy;
 
-  const int lrow = tid / C::CH, chunk = tid % C::CH;
   const int total_steps = (p.M + C::KP - 1) / C::KP;
   const int s_begin = split * p.steps_per_split;
   const int s_end = min(total_steps, s_begin + p.steps_per_split);
@@ -63,58 +80,73 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 vdy, vx[NT];
-  const int cdy = co0 + chunk * VEC, cx = ci0 + chunk * VEC;
-  auto gload = [&](int step) {
-    int pix = step * C::KP + lrow;
-    bool pok = pix < p.M;
-    int pp = pok ? pix : 0;
-    int n = pp / (p.OH * p.OW);
-    int rem = pp - n * (p.OH * p.OW);
-    int oh = rem / p.OW, ow = rem - oh * p.OW;
-    vdy = (u32x4){0u, 0u, 0u, 0u};
-    if (pok && cdy < p.Cout) vdy = *reinterpret_cast<const u32x4*>(dy + (size_t)pix * p.Cout + cdy);
+  // ---- DMA bookkeeping: this lane fills (row = wave*RPP + lane/CPR, physical chunk lane%CPR) of every tile
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const int drow = wave * C::RPP + lane / C::CPR;
+  const int lchunk = (lane % C::CPR) ^ C::swz(drow);
+  const int HW = p.OH * p.OW;
+  const long pix0 = (long)s_begin * C::KP;                       // first pixel of this split
+  const int n0 = (int)(((unsigned long long)(unsigned)pix0 * p.mul_hw) >> p.sh_hw);
+  const size_t img = (size_t)p.H * p.W * p.Cin;
+  const size_t x_left = ((size_t)p.N - n0) * img * sizeof(T);
+  const size_t dy_left = ((size_t)p.M - pix0) * p.Cout * sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(x + (size_t)n0 * img), 0, x_left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)x_left, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(dy + (size_t)pix0 * p.Cout), 0, dy_left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)dy_left, 0x00020000);
+  const int cdy = co0 + lchunk * VEC, cx = ci0 + lchunk * VEC;
+  const unsigned dy_lane = cdy < p.Cout ? (unsigned)cdy * (unsigned)sizeof(T) : OOB;
+  const unsigned x_lane = cx < p.Cin ? (unsigned)cx * (unsigned)sizeof(T) : OOB;
+  const unsigned dy_row_bytes = (unsigned)p.Cout * (unsigned)sizeof(T), x_pix_bytes = (unsigned)p.Cin * (unsigned)sizeof(T);
+
+  auto dma = [&](int stage, int step) {
+    unsigned char* base = smem + stage * STAGE_BYTES + wv * 1024;
+    const int pix = step * C::KP + drow;
+    const bool pok = pix < p.M;
+    const unsigned pp = pok ? (unsigned)pix : 0u;
+    const int n = (int)(((unsigned long long)pp * p.mul_hw) >> p.sh_hw);
+    const unsigned rem = pp - (unsigned)n * (unsigned)HW;
+    const int oh = (int)(((unsigned long long)rem * p.mul_w) >> p.sh_w);
+    const int ow = (int)rem - oh * p.OW;
+    wg_dma16(rs_dy, base, (pok && dy_lane != OOB) ? (unsigned)(pix - (int)pix0) * dy_row_bytes + dy_lane : OOB);
     const int hb = oh * p.stride - p.pad_h, wb = ow * p.stride - p.pad_w;
+    const int nrow = (n - n0) * p.H;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      int r = t / p.S, s = t - r * p.S;
-      int hs = hb + r, ws = wb + s;
-      bool ok = pok && cx < p.Cin && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(x + ((size_t)(n * p.H + hs) * p.W + ws) * p.Cin + cx);
-      vx[t] = v;
+      const int r = t / p.S, s = t - r * p.S;
+      const int hs = hb + r, ws = wb + s;
+      const bool ok = pok && x_lane != OOB && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
+      wg_dma16(rs_x, base + (1 + t) * TILE_BYTES, ok ? (unsigned)((nrow + hs) * p.W + ws) * x_pix_bytes + x_lane : OOB);
     }
-  };
-  auto lstore = [&]() {
-    unsigned char* base = smem + lrow * C::ROWSTRIDE + chunk * 16;
-    *reinterpret_cast<u32x4*>(base) = vdy;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4*>(base + (1 + t) * TILE_BYTES) = vx[t];
   };
 
   const int fr = lane & 15, fq = lane >> 4;
-  auto compute = [&]() {
+  auto compute = [&](int stage) {
+    const unsigned char* st = smem + stage * STAGE_BYTES;
     if constexpr (sizeof(T) == 2) {
       // transposing reads: lane 4q+p of a 16-lane group addresses row (kb+q), columns 4p..4p+3;
       // lane i receives column i of those 4 rows.  Group fq takes k rows 8fq..8fq+7.
       const int q = fr >> 2, pq = fr & 3;
+      const int row = 8 * fq + q;
+      const int sw = C::swz(row);  // == swz(row + 4)
       auto frag = [&](const unsigned char* tile, int col0) -> u32x4 {
-        const unsigned char* a0 = tile + (8 * fq + q) * C::ROWSTRIDE + (col0 + 4 * pq) * 2;
+        const int byte = (col0 + 4 * pq) * 2;
+        const unsigned char* a0 = tile + row * C::RB + ((((byte >> 4) ^ sw)) << 4) + (byte & 15);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0)));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0 + 4 * C::ROWSTRIDE)));
+            (__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0 + 4 * C::RB)));
         uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         return (u32x4){l2.x, l2.y, h2.x, h2.y};
       };
       u32x4 fa[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = frag(smem, wco * 32 + a * 16);
+      for (int a = 0; a < 2; ++a) fa[a] = frag(st, wco * 32 + a * 16);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         u32x4 fb[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) fb[b] = frag(smem + (1 + t) * TILE_BYTES, wci * 32 + b * 16);
+        for (int b = 0; b < 2; ++b) fb[b] = frag(st + (1 + t) * TILE_BYTES, wci * 32 + b * 16);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -127,17 +159,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int ks = 0; ks < C::KP / 4; ++ks) {
         const int krow = ks * 4 + fq;
+        const int sw = C::swz(krow);
+        auto rd = [&](const unsigned char* tile, int col) -> float {
+          return *reinterpret_cast<const float*>(tile + krow * C::RB + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
+        };
         float fa[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-          fa[a] = *reinterpret_cast<const float*>(smem + krow * C::ROWSTRIDE + (wco * 32 + a * 16 + fr) * 4);
+        for (int a = 0; a < 2; ++a) fa[a] = rd(st, wco * 32 + a * 16 + fr);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           float fb[2];
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            fb[b] = *reinterpret_cast<const float*>(smem + (1 + t) * TILE_BYTES + krow * C::ROWSTRIDE +
-                                                    (wci * 32 + b * 16 + fr) * 4);
+          for (int b = 0; b < 2; ++b) fb[b] = rd(st + (1 + t) * TILE_BYTES, wci * 32 + b * 16 + fr);
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -149,12 +182,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   };
 
   if (s_begin < s_end) {
-    gload(s_begin);
-    for (int step = s_begin; step < s_end; ++step) {
-      lstore();
-      __syncthreads();
-      if (step + 1 < s_end) gload(step + 1);
-      compute();
+    dma(0, s_begin);
+    __syncthreads();  // drains vmcnt: stage 0 has landed for every wave
+    for (int step = s_begin, k = 0; step < s_end; ++step, ++k) {
+      if (step + 1 < s_end) dma((k + 1) & 1, step + 1);  // buffer last read in iteration k-1, fenced by its barrier
+      compute(k & 1);
       __syncthreads();
     }
   }
@@ -175,6 +207,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             p.slab[(((size_t)split * RS + t) * p.Cout + co) * p.Cin + ci] = acc[t][a][b][j];
         }
       }
+}
+
+// exact unsigned division by d for dividends < 2^31: q = (x * m) >> sh
+void magic_div(unsigned d, unsigned& m, unsigned& sh) {
+  int l = 0;
+  while ((1u << l) < d) ++l;
+  m = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  sh = 31 + l;
 }
 
 // grad[co][ci][tap] (OIHW flattened) = sum_split slab[split][tap][co][ci]   (fixed order)
@@ -207,23 +247,34 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+template <typename T, int NT>
+int launch_wgrad_nt(WgradParams& p, dim3 grid, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)(1 + NT) * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<T, NT>), grid, dim3(256), lds, stream, p);
+  ECG_CHECK_LAUNCH("wgrad_kernel");
+  return 0;
+}
+
 template <typename T>
 int launch_wgrad(const ConvGeom& g, WgradParams& p, int nsplit, hipStream_t stream) {
   const int RS = g.R * g.S;
   dim3 grid(ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64), nsplit);
-  if (RS == 1) hipLaunchKernelGGL((wgrad_kernel<T, 1>), grid, dim3(256), 0, stream, p);
-  else if (RS == 3) hipLaunchKernelGGL((wgrad_kernel<T, 3>), grid, dim3(256), 0, stream, p);
-  else if (RS == 9) hipLaunchKernelGGL((wgrad_kernel<T, 9>), grid, dim3(256), 0, stream, p);
-  else ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: %dx%d filter unsupported (1, 3 or 9 taps)", g.R, g.S);
-  ECG_CHECK_LAUNCH("wgrad_kernel");
-  return 0;
+  if (RS == 1) return launch_wgrad_nt<T, 1>(p, grid, stream);
+  if (RS == 3) return launch_wgrad_nt<T, 3>(p, grid, stream);
+  if (RS == 9) return launch_wgrad_nt<T, 9>(p, grid, stream);
+  ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: %dx%d filter unsupported (1, 3 or 9 taps)", g.R, g.S);
 }
 
 int pick_nsplit(const ConvGeom& g, int kp) {
   long M = (long)g.N * g.OH * g.OW;
   int tiles = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
   int steps = ceil_div(M, kp);
-  int want = ceil_div(1024, tiles);  // ~4 workgroups per CU
+  int want = ceil_div(512, tiles);  // one resident round: 2 workgroups per CU (register-limited)
   int ns = want < 1 ? 1 : want;
   if (ns > steps) ns = steps;
   if (ns > 512) ns = 512;
@@ -251,9 +302,11 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
   WgradParams p;
   p.x = x; p.dy = dy; p.slab = (float*)workspace;
-  p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.OH = g.OH; p.OW = g.OW; p.Cout = g.Cout; p.S = g.S;
+  p.N = g.N; p.H = g.H; p.W = g.W; p.Cin = g.Cin; p.OH = g.OH; p.OW = g.OW; p.Cout = g.Cout; p.S = g.S;
   p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w; p.M = (int)M;
   p.steps_per_split = ceil_div(ceil_div(M, kp), ns);
+  magic_div((unsigned)(g.OH * g.OW), p.mul_hw, p.sh_hw);
+  magic_div((unsigned)g.OW, p.mul_w, p.sh_w);
   if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "conv wgrad: bad dtype %d", dtype);
   ecg_prof_begin(ECG_PROF_WGRAD, 2.0 * (double)M * g.Cout * g.R * g.S * g.Cin, stream);
   int rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, stream) : launch_wgrad<float>(g, p, ns, stream);
