@@ -33,10 +33,17 @@ struct StemParams {
 
 template <typename T> struct StemCfg;
 template <> struct StemCfg<bf16_t> { static constexpr int WPAD = 8; };   // row stride (KP + 8) bf16: 16-B reads conflict-free
-template <> struct StemCfg<float> { static constexpr int WPAD = 1; };
+template <> struct StemCfg<float> { static constexpr int WPAD = 4; };
 
-__device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patch, int n, int oh0, int ow0, int PH,
-                                                int PW, int PWS) {
+// tile / patch geometry per filter height (R = 7: 2-D stem, 8x16 output tile; R = 1: 1-D stem, 1x128)
+template <int R> struct StemDims {
+  static constexpr int TH = R == 1 ? 1 : 8, TW = R == 1 ? 128 : 16;
+  static constexpr int PH = (TH - 1) * 2 + R, PW = (TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+};
+
+template <int R>
+__device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patch, int n, int oh0, int ow0) {
+  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS;
   const int total = p.Cin * PH * PWS;
   const float* xin = p.x + (size_t)n * p.Cin * p.H * p.W;
   for (int i = threadIdx.x; i < total; i += 256) {
@@ -51,32 +58,39 @@ __device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patc
   }
 }
 
-template <typename T>
+template <typename T, int R>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TH = StemDims<R>::TH, TW = StemDims<R>::TW, PH = StemDims<R>::PH, PWS = StemDims<R>::PWS;
+  constexpr int VEC = Elem<T>::VEC;
   const int ksteps = (p.NG + 3) / 4;
   const int KP = ksteps * 32;
-  const int WS = KP + StemCfg<T>::WPAD;  // weight row stride (elements)
-  const int PH = (p.TH - 1) * 2 + p.R, PW = (p.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+  const int WS = KP + StemCfg<T>::WPAD;  // weight row stride (elements; rows stay 16-B aligned)
   T* sW = reinterpret_cast<T*>(smem);
   float* patch = reinterpret_cast<float*>(smem + align_up_dev((size_t)STEM_CO * WS * sizeof(T)));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  int bid = blockIdx.x;
+
+  // stage the packed weights once per workgroup (16-B vectors); the workgroup then walks its tiles
+  {
+    const T* wg = (const T*)p.wpk;
+    const int vpr = KP / VEC;  // vectors per row
+    for (int i = tid; i < STEM_CO * vpr; i += 256) {
+      int co = i / vpr, kv = i - co * vpr;
+      *reinterpret_cast<u32x4*>(sW + co * WS + kv * VEC) = *reinterpret_cast<const u32x4*>(wg + (size_t)co * KP + kv * VEC);
+    }
+  }
+  const int ntiles = p.N * p.tiles_h * p.tiles_w;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  int bid = tile;
   const int tw_i = bid % p.tiles_w;
   bid /= p.tiles_w;
   const int th_i = bid % p.tiles_h;
   const int n = bid / p.tiles_h;
-  const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
-
-  // stage weights (K-contiguous rows) and the input patch
-  const T* wg = (const T*)p.wpk;
-  for (int i = tid; i < STEM_CO * KP; i += 256) {
-    int co = i / KP, k = i - co * KP;
-    sW[co * WS + k] = wg[i];
-  }
-  stem_load_patch(p, patch, n, oh0, ow0, PH, PW, PWS);
+  const int oh0 = th_i * TH, ow0 = tw_i * TW;
+  __syncthreads();  // previous tile's patch fully consumed (and, first time, weights staged)
+  stem_load_patch<R>(p, patch, n, oh0, ow0);
   __syncthreads();
 
   f32x4 acc[4][2];
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int segs = p.TW / 16;
+  constexpr int segs = TW / 16;
   int prow[2], pcol[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   for (int ks = 0; ks < ksteps; ++ks) {
     int G = ks * 4 + fq;
     if (G >= p.NG) G = p.NG - 1;  // padded groups carry zero weights; keep the read in bounds
-    const int c = G / p.R, r = G - c * p.R;
+    const int c = G / R, r = G - c * R;
     float bv[2][8];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
       for (int g = 0; g < 4; ++g) {
         int G2 = ks * 4 + g;
         if (G2 >= p.NG) G2 = p.NG - 1;
-        const int c2 = G2 / p.R, r2 = G2 - c2 * p.R;
+        const int c2 = G2 / R, r2 = G2 - c2 * R;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int s = hf * 4 + fq;
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
         }
       }
       if (fr == 0) {
-        float* row = p.stats + (size_t)(blockIdx.x * 4 + wave) * 2 * STEM_CO;
+        float* row = p.stats + (size_t)(tile * 4 + wave) * 2 * STEM_CO;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           row[ch0 + j] = s1[j];
@@ -198,17 +212,18 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
       }
     }
   }
+  }  // tile loop
 }
 
 // ---------------------------------------------------------------------------------------------------
 // wgrad: slab[split][co][kidx] = sum over this split's tiles of dy[pix][co] * patch(pix, kidx)
 // wave w owns k-tiles {w, w+4, w+8} (16 kidx each) x all 4 co-tiles.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int R>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int DYS = sizeof(T) == 2 ? 144 : 320;  // dy row stride in bytes (64 ch + pad)
-  const int PH = (p.TH - 1) * 2 + p.R, PW = (p.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+  constexpr int TH = StemDims<R>::TH, TW = StemDims<R>::TW, PH = StemDims<R>::PH, PWS = StemDims<R>::PWS;
   unsigned char* sDY = smem;                                  // [128 pix][DYS]
   float* patch = reinterpret_cast<float*>(smem + 128 * DYS);  // [Cin][PH][PWS]
 
@@ -216,7 +231,6 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int NK = p.NG * 8;
   const int ktiles = (NK + 15) / 16;
-  const int segs = p.TW / 16;
   const int total_tiles = p.N * p.tiles_h * p.tiles_w;
   const int t_begin = blockIdx.x * p.tiles_per_split;
   const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
@@ -237,8 +251,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     int kk = kok[b] ? kidx : 0;
     int G = kk >> 3;
     ksx[b] = kk & 7;
-    kc[b] = G / p.R;
-    krr[b] = G - kc[b] * p.R;
+    kc[b] = G / R;
+    krr[b] = G - kc[b] * R;
   }
 
   const T* dy = (const T*)p.y;
@@ -248,13 +262,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     bid /= p.tiles_w;
     const int th_i = bid % p.tiles_h;
     const int n = bid / p.tiles_h;
-    const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+    const int oh0 = th_i * TH, ow0 = tw_i * TW;
     __syncthreads();  // previous tile's LDS fully consumed
     // dy tile: pixel index within tile = trow*TW + tcol ; 16 B per thread-vector
     constexpr int CH = 64 * (int)sizeof(T) / 16;
     for (int i = tid; i < 128 * CH; i += 256) {
       int pix = i / CH, chunk = i % CH;
-      int trow = pix / p.TW, tcol = pix % p.TW;
+      int trow = pix / TW, tcol = pix % TW;
       int oh = oh0 + trow, ow = ow0 + tcol;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (oh < p.OH && ow < p.OW)
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
                                             chunk * (16 / (int)sizeof(T)));
       *reinterpret_cast<u32x4*>(sDY + pix * DYS + chunk * 16) = v;
     }
-    stem_load_patch(p, patch, n, oh0, ow0, PH, PW, PWS);
+    stem_load_patch<R>(p, patch, n, oh0, ow0);
     __syncthreads();
 
     if constexpr (sizeof(T) == 2) {
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
         }
         // B: 8 consecutive pixels (st*32 + 8*fq + j) of one kidx
         const int pix0 = st * 32 + 8 * fq;
-        const int trow = pix0 / p.TW, tcol0 = pix0 % p.TW;  // 8 | 16 | TW: the 8 pixels share a row
+        const int trow = pix0 / TW, tcol0 = pix0 % TW;  // 8 | 16 | TW: the 8 pixels share a row
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           float bv[8];
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     } else {
       for (int st = 0; st < 32; ++st) {  // 4 pixels per step
         const int pix = st * 4 + fq;
-        const int trow = pix / p.TW, tcol = pix % p.TW;
+        const int trow = pix / TW, tcol = pix % TW;
         float fa[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const float*>(sDY + pix * DYS + (a * 16 + fr) * 4);
@@ -418,19 +432,23 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   fill_params(p, s, N, Cin, H, W, R);
   p.x = x; p.wpk = wpk; p.y = y; p.bias = bias; p.stats = stats;
   const size_t esz = dtype_size(dtype);
-  const int WS = s.KP + (dtype == ECGMM_BF16 ? 8 : 1);
+  const int WS = s.KP + (dtype == ECGMM_BF16 ? 8 : 4);
   size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + patch_bytes(s, Cin, R);
-  dim3 grid(N * s.tiles_h * s.tiles_w);
+  const int ntiles = N * s.tiles_h * s.tiles_w;
+  dim3 grid(ntiles < 2048 ? ntiles : 2048);  // persistent: each workgroup stages the weights once, then walks tiles
   ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, stream);
   if (dtype == ECGMM_BF16) {
-    hipLaunchKernelGGL(stem_fwd_kernel<bf16_t>, grid, dim3(256), lds, stream, p);
+    if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1>), grid, dim3(256), lds, stream, p);
   } else if (dtype == ECGMM_F32) {
     static bool once = false;
     if (!once) {
-      (void)hipFuncSetAttribute((const void*)stem_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      (void)hipFuncSetAttribute((const void*)stem_fwd_kernel<float, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      (void)hipFuncSetAttribute((const void*)stem_fwd_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
       once = true;
     }
-    hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, stream, p);
+    if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<float, 7>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_fwd_kernel<float, 1>), grid, dim3(256), lds, stream, p);
   } else {
     ECG_FAIL(ECGMM_ERR_DTYPE, "stem: bad dtype %d", dtype);
   }
@@ -464,8 +482,13 @@ int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int a
   size_t lds = 128 * (size_t)(dtype == ECGMM_BF16 ? 144 : 320) + patch_bytes(s, Cin, R);
   if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "stem wgrad: bad dtype %d", dtype);
   ecg_prof_begin(ECG_PROF_STEM_WGRAD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, stream);
-  if (dtype == ECGMM_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(grid), dim3(256), lds, stream, p);
+  if (dtype == ECGMM_BF16) {
+    if (R == 7) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, 7>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, 1>), dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    if (R == 7) hipLaunchKernelGGL((stem_wgrad_kernel<float, 7>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_wgrad_kernel<float, 1>), dim3(grid), dim3(256), lds, stream, p);
+  }
   ecg_prof_end(stream);
   ECG_CHECK_LAUNCH("stem_wgrad");
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_CO * s.NG * 7, 16)), dim3(256), 0, stream,
