@@ -43,21 +43,26 @@ __global__ void linear_dgrad_kernel(const float* __restrict__ dy, const float* _
   }
 }
 
-// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o]   (fixed summation order)
-__global__ void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                    float* __restrict__ db, int B, int In, int Out, int accumulate) {
-  long total = (long)Out * In;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total + Out; e += (long)gridDim.x * blockDim.x) {
+// dw[o][i] = sum_b dy[b][o] x[b][i];  db[o] = sum_b dy[b][o]   (one wave per output element; fixed order)
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dw, float* __restrict__ db, int B, int In,
+                                                           int Out, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const long total = (long)Out * In;
+  long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long e = wid; e < total + Out; e += nw) {
+    float s = 0.f;
     if (e < total) {
-      int o = (int)(e / In), i = (int)(e % In);
-      float s = 0.f;
-      for (int b = 0; b < B; ++b) s += dy[(size_t)b * Out + o] * x[(size_t)b * In + i];
-      dw[e] = accumulate ? dw[e] + s : s;
+      const int o = (int)(e / In), i = (int)(e % In);
+      for (int b = lane; b < B; b += 64) s += dy[(size_t)b * Out + o] * x[(size_t)b * In + i];
+      s = wave_sum(s);
+      if (lane == 0) dw[e] = accumulate ? dw[e] + s : s;
     } else if (db) {
-      int o = (int)(e - total);
-      float s = 0.f;
-      for (int b = 0; b < B; ++b) s += dy[(size_t)b * Out + o];
-      db[o] = accumulate ? db[o] + s : s;
+      const int o = (int)(e - total);
+      for (int b = lane; b < B; b += 64) s += dy[(size_t)b * Out + o];
+      s = wave_sum(s);
+      if (lane == 0) db[o] = accumulate ? db[o] + s : s;
     }
   }
 }
@@ -469,7 +474,7 @@ int ecg_linear_dgrad_valu(const float* dy, const float* w, float* dx, int B, int
 }
 int ecg_linear_wgrad_valu(const float* dy, const float* x, float* dw, float* db, int B, int In, int Out,
                           int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(g1d((long)Out * In + Out)), dim3(256), 0, s, dy, x, dw, db, B, In, Out,
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(g1d((long)Out * In + Out, 4)), dim3(256), 0, s, dy, x, dw, db, B, In, Out,
                      accumulate);
   ECG_CHECK_LAUNCH("linear_wgrad");
   return 0;
