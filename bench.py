@@ -150,7 +150,13 @@ def main():
 
     model, batch, labels, loss_fn = build(args, device)
     flatten(model)
-    ddp = DataParallel(model) if world > 1 else None
+    # ECGMM_FORCE_DDP=1 rehearses the multi-rank code path (hooks, comm stream, bucketed all-reduce) on one rank
+    force_ddp = os.environ.get("ECGMM_FORCE_DDP") == "1"
+    if force_ddp and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    ddp = DataParallel(model, force=force_ddp) if (world > 1 or force_ddp) else None
     opt = FusedAdam(model.parameters(), lr=1e-4, grad_scale=1.0 / world)
 
     def step():
@@ -232,7 +238,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

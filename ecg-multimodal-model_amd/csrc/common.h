@@ -93,6 +93,19 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15) with VALU-only DPP moves (no ds_bpermute /
+// LDS traffic): quad xor-1, quad xor-2, half-row mirror, row mirror.  Every lane ends with the total.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 static inline size_t dtype_size(int dt) { return dt == ECGMM_BF16 ? 2 : 4; }

@@ -315,11 +315,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       // butterfly over the 16 pixel lanes, then lane fr==0 of each quad writes 4 channels
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          s1[j] += __shfl_xor(s1[j], o, 64);
-          s2[j] += __shfl_xor(s2[j], o, 64);
-        }
+        s1[j] = row16_sum(s1[j]);
+        s2[j] = row16_sum(s2[j]);
       }
       if (fr == 0) {
         float* row = p.stats + (size_t)(mt * 2 + wp) * 2 * p.Cd;

@@ -58,6 +58,45 @@ __device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patc
   }
 }
 
+// Split form for software pipelining: fetch the NEXT tile's patch into registers while the current
+// tile computes, write it to LDS after the barrier.  NPRE * 256 >= Cin * PH * PWS (checked on the host).
+constexpr int NPRE = 16;
+template <int R>
+__device__ __forceinline__ void stem_fetch_patch(const StemParams& p, float (&pre)[NPRE], int n, int oh0, int ow0) {
+  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS;
+  const int total = p.Cin * PH * PWS;
+  const float* xin = p.x + (size_t)n * p.Cin * p.H * p.W;
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    int pw = i % PWS;
+    int t = i / PWS;
+    int ph = t % PH, c = t / PH;
+    int ih = oh0 * 2 - p.pad_h + ph, iw = ow0 * 2 - 3 + pw;
+    float v = 0.f;
+    if (i < total && pw < PW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+      v = xin[((size_t)c * p.H + ih) * p.W + iw];
+    pre[k] = v;
+  }
+}
+template <int R>
+__device__ __forceinline__ void stem_store_patch(const StemParams& p, float* patch, const float (&pre)[NPRE]) {
+  const int total = p.Cin * StemDims<R>::PH * StemDims<R>::PWS;
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < total) patch[i] = pre[k];
+  }
+}
+__device__ __forceinline__ void stem_tile_origin(const StemParams& p, int tile, int TH, int TW, int& n, int& oh0, int& ow0) {
+  const int tw_i = tile % p.tiles_w;
+  tile /= p.tiles_w;
+  const int th_i = tile % p.tiles_h;
+  n = tile / p.tiles_h;
+  oh0 = th_i * TH;
+  ow0 = tw_i * TW;
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -82,16 +121,25 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
   }
   const int ntiles = p.N * p.tiles_h * p.tiles_w;
+  float pre[NPRE];
+  {
+    int n_, oh_, ow_;
+    if ((int)blockIdx.x < ntiles) {
+      stem_tile_origin(p, blockIdx.x, TH, TW, n_, oh_, ow_);
+      stem_fetch_patch<R>(p, pre, n_, oh_, ow_);
+    }
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  int bid = tile;
-  const int tw_i = bid % p.tiles_w;
-  bid /= p.tiles_w;
-  const int th_i = bid % p.tiles_h;
-  const int n = bid / p.tiles_h;
-  const int oh0 = th_i * TH, ow0 = tw_i * TW;
+  int n, oh0, ow0;
+  stem_tile_origin(p, tile, TH, TW, n, oh0, ow0);
   __syncthreads();  // previous tile's patch fully consumed (and, first time, weights staged)
-  stem_load_patch<R>(p, patch, n, oh0, ow0);
+  stem_store_patch<R>(p, patch, pre);
   __syncthreads();
+  if (tile + (int)gridDim.x < ntiles) {  // next tile's patch streams in underneath this tile's MFMAs
+    int n_, oh_, ow_;
+    stem_tile_origin(p, tile + gridDim.x, TH, TW, n_, oh_, ow_);
+    stem_fetch_patch<R>(p, pre, n_, oh_, ow_);
+  }
 
   f32x4 acc[4][2];
 #pragma unroll
@@ -196,11 +244,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     if (p.stats) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          s1[j] += __shfl_xor(s1[j], o, 64);
-          s2[j] += __shfl_xor(s2[j], o, 64);
-        }
+        s1[j] = row16_sum(s1[j]);
+        s2[j] = row16_sum(s2[j]);
       }
       if (fr == 0) {
         float* row = p.stats + (size_t)(tile * 4 + wave) * 2 * STEM_CO;
@@ -256,17 +301,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   }
 
   const T* dy = (const T*)p.y;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    int bid = tile;
-    const int tw_i = bid % p.tiles_w;
-    bid /= p.tiles_w;
-    const int th_i = bid % p.tiles_h;
-    const int n = bid / p.tiles_h;
-    const int oh0 = th_i * TH, ow0 = tw_i * TW;
-    __syncthreads();  // previous tile's LDS fully consumed
-    // dy tile: pixel index within tile = trow*TW + tcol ; 16 B per thread-vector
-    constexpr int CH = 64 * (int)sizeof(T) / 16;
-    for (int i = tid; i < 128 * CH; i += 256) {
+  constexpr int CH = 64 * (int)sizeof(T) / 16;  // 16-B chunks per dy row
+  constexpr int NDY = 128 * CH / 256;           // dy vectors per thread per tile (4 bf16 / 8 f32)
+  float pre[NPRE];
+  u32x4 pdy[NDY];
+  auto fetch = [&](int tile) {
+    int n, oh0, ow0;
+    stem_tile_origin(p, tile, TH, TW, n, oh0, ow0);
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int i = tid + 256 * k;
       int pix = i / CH, chunk = i % CH;
       int trow = pix / TW, tcol = pix % TW;
       int oh = oh0 + trow, ow = ow0 + tcol;
@@ -274,10 +318,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
       if (oh < p.OH && ow < p.OW)
         v = *reinterpret_cast<const u32x4*>(dy + (((size_t)n * p.OH + oh) * p.OW + ow) * STEM_CO +
                                             chunk * (16 / (int)sizeof(T)));
-      *reinterpret_cast<u32x4*>(sDY + pix * DYS + chunk * 16) = v;
+      pdy[k] = v;
     }
-    stem_load_patch<R>(p, patch, n, oh0, ow0);
+    stem_fetch_patch<R>(p, pre, n, oh0, ow0);
+  };
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // previous tile's LDS fully consumed
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+      const int i = tid + 256 * k;
+      *reinterpret_cast<u32x4*>(sDY + (i / CH) * DYS + (i % CH) * 16) = pdy[k];
+    }
+    stem_store_patch<R>(p, patch, pre);
     __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);  // streams in underneath this tile's MFMAs
 
     if constexpr (sizeof(T) == 2) {
       const int q = fr >> 2, pq = fr & 3;
@@ -392,6 +447,10 @@ int stem_shape(int Cin, int H, int W, int R, StemShape& s) {
   s.tiles_h = ceil_div(s.OH, s.TH);
   s.tiles_w = ceil_div(s.OW, s.TW);
   s.KP = ((s.NG + 3) / 4) * 32;
+  {
+    int PH = (s.TH - 1) * 2 + R, PW = (s.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+    if (Cin * PH * PWS > 16 * 256) ECG_FAIL(ECGMM_ERR_SHAPE, "stem: input patch of %d channels exceeds the prefetch registers", Cin);
+  }
   return 0;
 }
 void fill_params(StemParams& p, const StemShape& s, int N, int Cin, int H, int W, int R) {

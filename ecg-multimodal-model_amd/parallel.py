@@ -44,7 +44,7 @@ class DataParallel(torch.nn.Module):
     with ``overlap=True``, during) backward.  Gradients are SUMMED; pass ``grad_scale=1/world`` to
     FusedAdam (``self.grad_scale``)."""
 
-    def __init__(self, module, process_group=None, bucket_mb=32, overlap=True):
+    def __init__(self, module, process_group=None, bucket_mb=32, overlap=True, force=False):
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -56,8 +56,9 @@ class DataParallel(torch.nn.Module):
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self._pending = []
         self._comm_stream = None
-        self.overlap = overlap and self.world > 1 and self.flat_g.is_cuda
-        if self.world > 1:
+        self.force = force and dist.is_initialized()
+        self.overlap = overlap and (self.world > 1 or self.force) and self.flat_g.is_cuda
+        if self.world > 1 or self.force:
             dist.broadcast(self.flat_p, src=0, group=self.pg)
             for b in module.buffers():
                 dist.broadcast(b, src=0, group=self.pg)
@@ -116,7 +117,7 @@ class DataParallel(torch.nn.Module):
     def reduce_gradients(self):
         """All-reduce whatever the stage hooks have not already shipped, then make the compute
         stream wait for the comm stream."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         done = sorted(getattr(self, "_done_ranges", []))
         total = self.flat_g.numel()
