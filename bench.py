@@ -124,7 +124,7 @@ def cpu_baseline(seconds):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds or n >= 50:
+        if el > seconds or n >= 2000:
             break
     return {"value": round(B * n / el, 2), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n} train steps of oracle.ECGMultimodalModel (torch {torch.__version__} CPU fp32), batch 8, "
@@ -192,20 +192,28 @@ def main():
     roof = None
     if prof:
         nk = len(PROF_KINDS)
-        ms, fl, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
-        rc = lib.ecgmm_prof_collect(nk, ms, fl, cnt)
+        ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
+        rc = lib.ecgmm_prof_collect(nk, ms, fl, by, cnt)
         lib.ecgmm_prof_enable(0)
-        kinds = {PROF_KINDS[i]: {"ms": ms[i], "flops": fl[i], "launches": int(cnt[i])} for i in range(nk)}
+        kinds = {PROF_KINDS[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": int(cnt[i])} for i in range(nk)}
         dom = max(("conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad"), key=lambda k: kinds[k]["ms"])
         # the implicit-GEMM kernel template (fwd + dgrad instantiations) is one kernel class
         ig_ms = kinds["conv_igemm_fwd"]["ms"] + kinds["conv_igemm_dgrad"]["ms"]
         ig_fl = kinds["conv_igemm_fwd"]["flops"] + kinds["conv_igemm_dgrad"]["flops"]
         ig_n = kinds["conv_igemm_fwd"]["launches"] + kinds["conv_igemm_dgrad"]["launches"]
+        ig_by = kinds["conv_igemm_fwd"]["bytes"] + kinds["conv_igemm_dgrad"]["bytes"]
+        # HBM traffic per launch from the rocprofv3 PMC passes of this same command (cannot be collected from
+        # inside the process): tools/roofline_traffic.py -> profiles/r01_igemm_traffic.json
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
+        if args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and os.path.exists(tpath):
+            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"], 1)
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         if rc == 0 and ig_ms > 0:
             ach = ig_fl / (ig_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad)", "achieved": round(ach, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(ig_by / max(ig_n, 1), 1),
                     "launches": ig_n, "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
                     "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),
                     "by_kind": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),

@@ -386,7 +386,12 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
   const int vec = dtype == ECGMM_BF16 ? 8 : 4;
   if (p.Cs % vec != 0) ECG_FAIL(ECGMM_ERR_SHAPE, "conv: reduction channels %d not a multiple of %d", p.Cs, vec);
   if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "conv: bad dtype %d", dtype);
-  ecg_prof_begin(mode == 0 ? ECG_PROF_IGEMM_FWD : ECG_PROF_IGEMM_DGRAD, conv_flops(g), stream);
+  {  // algorithmic bytes: source and destination tensors once each (+ addend), + the packed weights
+    const double esz = (double)dtype_size(dtype);
+    double bytes = esz * ((double)g.N * p.Hs * p.Ws * p.Cs + (double)M * p.Cd * (addend ? 2.0 : 1.0) +
+                          (double)g.R * g.S * g.Cin * g.Cout);
+    ecg_prof_begin(mode == 0 ? ECG_PROF_IGEMM_FWD : ECG_PROF_IGEMM_DGRAD, conv_flops(g), bytes, stream);
+  }
   int rc = dtype == ECGMM_BF16 ? launch_T<bf16_t>(p, mode, stream) : launch_T<float>(p, mode, stream);
   ecg_prof_end(stream);
   return rc;

@@ -495,7 +495,8 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + patch_bytes(s, Cin, R);
   const int ntiles = N * s.tiles_h * s.tiles_w;
   dim3 grid(ntiles < 2048 ? ntiles : 2048);  // persistent: each workgroup stages the weights once, then walks tiles
-  ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, stream);
+  ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7,
+                 4.0 * N * Cin * H * W + (double)dtype_size(dtype) * N * s.OH * s.OW * STEM_CO, stream);
   if (dtype == ECGMM_BF16) {
     if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7>), grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1>), grid, dim3(256), lds, stream, p);
@@ -540,7 +541,8 @@ int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int a
   const int grid = ceil_div(total, p.tiles_per_split);
   size_t lds = 128 * (size_t)(dtype == ECGMM_BF16 ? 144 : 320) + patch_bytes(s, Cin, R);
   if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "stem wgrad: bad dtype %d", dtype);
-  ecg_prof_begin(ECG_PROF_STEM_WGRAD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, stream);
+  ecg_prof_begin(ECG_PROF_STEM_WGRAD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7,
+                 4.0 * N * Cin * H * W + (double)dtype_size(dtype) * N * s.OH * s.OW * STEM_CO, stream);
   if (dtype == ECGMM_BF16) {
     if (R == 7) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, 7>), dim3(grid), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, 1>), dim3(grid), dim3(256), lds, stream, p);

@@ -308,7 +308,10 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
   magic_div((unsigned)(g.OH * g.OW), p.mul_hw, p.sh_hw);
   magic_div((unsigned)g.OW, p.mul_w, p.sh_w);
   if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "conv wgrad: bad dtype %d", dtype);
-  ecg_prof_begin(ECG_PROF_WGRAD, 2.0 * (double)M * g.Cout * g.R * g.S * g.Cin, stream);
+  ecg_prof_begin(ECG_PROF_WGRAD, 2.0 * (double)M * g.Cout * g.R * g.S * g.Cin,
+                 (double)dtype_size(dtype) * ((double)g.N * g.H * g.W * g.Cin + (double)M * g.Cout) +
+                     4.0 * g.R * g.S * g.Cin * g.Cout,
+                 stream);
   int rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, stream) : launch_wgrad<float>(g, p, ns, stream);
   ecg_prof_end(stream);
   ECG_TRY(rc);

@@ -86,7 +86,7 @@ int ecg_linear_bwd(const float* dz, const float* x, const float* w, float* dx, f
 
 // prof.hip
 enum { ECG_PROF_IGEMM_FWD = 0, ECG_PROF_IGEMM_DGRAD = 1, ECG_PROF_WGRAD = 2, ECG_PROF_STEM_FWD = 3, ECG_PROF_STEM_WGRAD = 4 };
-void ecg_prof_begin(int kind, double flops, hipStream_t s);
+void ecg_prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void ecg_prof_end(hipStream_t s);
 
 // bump allocator over a caller-owned workspace (base == nullptr: measure only)

@@ -4,7 +4,7 @@
 
 namespace {
 constexpr int MAXEV = 8192;
-struct Rec { int kind; double flops; };
+struct Rec { int kind; double flops; double bytes; };
 bool g_on = false;
 int g_n = 0;
 hipEvent_t g_start[MAXEV], g_stop[MAXEV];
@@ -13,11 +13,12 @@ Rec g_rec[MAXEV];
 int g_open = -1;
 }  // namespace
 
-void ecg_prof_begin(int kind, double flops, hipStream_t s) {
+void ecg_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
   if (!g_on || g_n >= MAXEV) { g_open = -1; return; }
   g_open = g_n++;
   g_rec[g_open].kind = kind;
   g_rec[g_open].flops = flops;
+  g_rec[g_open].bytes = bytes;
   (void)hipEventRecord(g_start[g_open], s);
 }
 void ecg_prof_end(hipStream_t s) {
@@ -41,14 +42,14 @@ extern "C" int ecgmm_prof_enable(int on) {
 }
 
 // Synchronises the recorded events and accumulates per-kind totals; nkinds entries each.
-extern "C" int ecgmm_prof_collect(int nkinds, double* ms, double* flops, int64_t* count) {
-  for (int k = 0; k < nkinds; ++k) { ms[k] = 0; flops[k] = 0; count[k] = 0; }
+extern "C" int ecgmm_prof_collect(int nkinds, double* ms, double* flops, double* bytes, int64_t* count) {
+  for (int k = 0; k < nkinds; ++k) { ms[k] = 0; flops[k] = 0; bytes[k] = 0; count[k] = 0; }
   for (int i = 0; i < g_n; ++i) {
     if (hipEventSynchronize(g_stop[i]) != hipSuccess) ECG_FAIL(ECGMM_ERR_LAUNCH, "prof: event sync failed");
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_start[i], g_stop[i]) != hipSuccess) ECG_FAIL(ECGMM_ERR_LAUNCH, "prof: elapsed failed");
     int k = g_rec[i].kind;
-    if (k >= 0 && k < nkinds) { ms[k] += t; flops[k] += g_rec[i].flops; count[k] += 1; }
+    if (k >= 0 && k < nkinds) { ms[k] += t; flops[k] += g_rec[i].flops; bytes[k] += g_rec[i].bytes; count[k] += 1; }
   }
   int n = g_n;
   g_n = 0;

@@ -90,7 +90,7 @@ SIGNATURES = {
     "ecgmm_adam": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
     "ecgmm_axpby": (i32, [f32, vp, f32, vp, i64, vp]),
     "ecgmm_prof_enable": (i32, [i32]),
-    "ecgmm_prof_collect": (i32, [i32, P(f64), P(f64), P(i64)]),
+    "ecgmm_prof_collect": (i32, [i32, P(f64), P(f64), P(f64), P(i64)]),
 }
 
 _lib = None

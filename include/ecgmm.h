@@ -208,9 +208,10 @@ int ecgmm_axpby(float a, const float* x, float b, float* y, int64_t n, void* str
 
 /* Measurement only (no reference counterpart): HIP-event timing of the conv kernels on their launch
  * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad.  collect()
- * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / launches. */
+ * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / algorithmic
+ * HBM bytes / launches. */
 int ecgmm_prof_enable(int on);
-int ecgmm_prof_collect(int nkinds, double* ms, double* flops, int64_t* count);
+int ecgmm_prof_collect(int nkinds, double* ms, double* flops, double* bytes, int64_t* count);
 
 #ifdef __cplusplus
 }
