@@ -59,7 +59,8 @@ class _Scratch:
 
     @classmethod
     def get(cls, key, nbytes, device):
-        k = (key, device.index)
+        # one buffer per (use, device, STREAM): encoders may run concurrently on different streams
+        k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)
         b = cls._bufs.get(k)
         if b is None or b.numel() < nbytes:
             b = new_bytes(nbytes, device)

@@ -187,12 +187,28 @@ class ECGMultimodalModel(nn.Module):
         print(f"Image encoder weights loaded from {weight_path} (load_fc={load_fc}, {len(new_state)} tensors)")
 
     def forward(self, image, ecg_signal, clinical):
-        img_feat = self.image_norm(self.image_encoder(image))
-
         ecg_signal = ecg_signal.unsqueeze(1)
-        signal_feat = self.signal_norm(self.signal_encoder(ecg_signal))
-
-        clinical_feat = self.clinical_norm(self.clinical_encoder(clinical))
+        if image.is_cuda and getattr(self.config, "overlap_encoders", True):
+            # The three encoders are independent until the fusion: run the (small-kernel) signal and
+            # clinical branches on a side HIP stream underneath the image encoder's launches.  autograd
+            # replays each backward node on the stream its forward ran on, so the backward overlaps too.
+            main = torch.cuda.current_stream(image.device)
+            side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(image.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                signal_raw = self.signal_encoder(ecg_signal)
+                clinical_raw = self.clinical_encoder(clinical)
+            image_raw = self.image_encoder(image)
+            main.wait_stream(side)
+            signal_raw.record_stream(main)
+            clinical_raw.record_stream(main)
+        else:
+            image_raw = self.image_encoder(image)
+            signal_raw = self.signal_encoder(ecg_signal)
+            clinical_raw = self.clinical_encoder(clinical)
+        img_feat = self.image_norm(image_raw)
+        signal_feat = self.signal_norm(signal_raw)
+        clinical_feat = self.clinical_norm(clinical_raw)
 
         img_logits = self.image_classifier(img_feat)
         signal_logits = self.signal_classifier(signal_feat)
