@@ -208,9 +208,11 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_kernel(BnBwdParams p) {
   const int cpr = p.C / VEC, rpi = EW_THREADS / cpr;
   const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
   const int c0 = chunk * VEC;
-  float mean[VEC], inv[VEC], k1[VEC], k2[VEC], k3[VEC], a1[VEC], a2[VEC];
+  float mean[VEC], inv[VEC], k1[VEC], k2[VEC], k3[VEC], a1[VEC], a2[VEC], msc[VEC], msh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
+    msc[j] = p.coef[c0 + j];
+    msh[j] = p.coef[p.C + c0 + j];
     mean[j] = p.coef[2 * p.C + c0 + j];
     inv[j] = p.coef[3 * p.C + c0 + j];
     a1[j] = a2[j] = 0.f;
@@ -227,7 +229,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_kernel(BnBwdParams p) {
     float d[VEC], m[VEC], v[VEC];
     unpack16<T>(ld16(dout + r * p.C + c0), d);
     unpack16<T>(ld16(y + r * p.C + c0), v);
-    if (mref) {
+    if (mref == y) {
+      // maskref aliasing y: the ReLU input was bn(y) itself, so the mask is recomputed through the
+      // BatchNorm affine instead of reading the activated tensor (one tensor read less)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[j] = (v[j] * msc[j] + msh[j]) > 0.f ? d[j] : 0.f;
+    } else if (mref) {
       unpack16<T>(ld16(mref + r * p.C + c0), m);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) d[j] = m[j] > 0.f ? d[j] : 0.f;

@@ -303,7 +303,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
         ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, s));
       ECG_TRY(ecg_conv_igemm(dt, 1, g2, q.dy, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
       // a1 = relu(bn1(y1))
-      ECG_TRY(ecg_bn_bwd(dt, q.da, b.a1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
+      ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1 /* mask recomputed from y1 */, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
                          G(grads, k.p_bn1 + 1), q.dy, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
       if (G(grads, k.p_conv1))
         ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, s));

@@ -320,7 +320,7 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
                          G(grads, p + 7), q.dy, q.dz, G(grads, p + 5), M, k.cout, q.bn_scratch, s));
       if (G(grads, p + 4)) ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, p + 4), 0, q.wg_ws, q.wg_bytes, s));
       ECG_TRY(ecg_conv_igemm(dt, 1, g2, q.dy, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
-      ECG_TRY(ecg_bn_bwd(dt, q.da, b.a1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, p + 2), G(grads, p + 2),
+      ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1 /* mask recomputed from y1 */, nullptr, nullptr, 1, b.y1, b.coef1, P(params, p + 2), G(grads, p + 2),
                          G(grads, p + 3), q.dy, nullptr, G(grads, p + 1), M, k.cout, q.bn_scratch, s));
       if (G(grads, p + 0)) ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy, G(grads, p + 0), 0, q.wg_ws, q.wg_bytes, s));
       if (k.down) {

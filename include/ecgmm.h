@@ -146,6 +146,7 @@ int ecgmm_bn_act(int dtype, const void* y, const float* coef, const void* res, c
                  int rows_per_sample, int relu, void* out, int64_t M, int C, void* stream);
 /* BatchNorm backward with the ReLU mask / SE gate folded in:
  *   dz = [maskref > 0] * dout * gate[n][c] + addc[n][c];  dy, dgamma, dbeta; dz_out = masked dout;
+ *   (maskref == y: the mask is recomputed as bn(y) > 0, saving the read of the activated tensor)
  *   dbias (nullable) = column sum of dy (Conv1d bias gradient). scratch: ecgmm_bn_bwd_scratch bytes */
 size_t ecgmm_bn_bwd_scratch(int dtype, int64_t M, int C);
 int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
