@@ -12,6 +12,8 @@
 //   fc.weight, fc.bias
 // Buffer table order (60 entries): per BatchNorm in the same walk: running_mean, running_var,
 //   num_batches_tracked (int64).
+#include <stdlib.h>
+
 #include "ops.h"
 
 namespace {
@@ -131,7 +133,9 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
 struct BwdWs {
   void* X[2];   // gradient w.r.t. block outputs (ping-pong)
   void* dz;     // masked residual-branch gradient
-  void* dy;     // gradient w.r.t. a raw conv output
+  void* dy;     // gradient w.r.t. conv2's raw output
+  void* dy1;    // gradient w.r.t. conv1's raw output (separate: the side-stream wgrad may still read dy)
+  void* dyd;    // gradient w.r.t. the downsample conv's raw output
   void* da;     // gradient w.r.t. a1
   void* dtmp;   // downsample-path input gradient
   void* big0;   // stem: dz0
@@ -150,6 +154,8 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   for (int i = 0; i < 2; ++i) w.X[i] = a.take_bytes(r.max_act * es);
   w.dz = a.take_bytes(r.max_act * es);
   w.dy = a.take_bytes(r.max_act * es);
+  w.dy1 = a.take_bytes(r.max_act * es);
+  w.dyd = a.take_bytes(r.max_act * es);
   w.da = a.take_bytes(r.max_act * es);
   w.dtmp = a.take_bytes(r.max_act * es);
   size_t big = (size_t)N * r.H1 * r.W1 * 64;
@@ -177,6 +183,49 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   w.lin_bytes = ecg_linear_bwd_scratch(N, 512, r.d.out_dim);
   w.lin_ws = a.take_bytes(w.lin_bytes);
   w.bytes = align_up(a.off, 256);
+}
+
+// ---- side stream for the weight-gradient kernels -------------------------------------------------
+// wgrad only feeds the optimizer, so it is taken off the critical path dgrad -> BN-backward -> dgrad:
+// it runs on a library-owned HIP stream, forked from / joined to the caller's stream with events
+// (all asynchronous and capturable; every call joins before it returns, so to the caller the work is
+// still ordered on the stream it passed).  MFMA-bound wgrad overlaps the HBM-bound BN passes.
+struct Side {
+  hipStream_t s = nullptr;
+  hipEvent_t ev[32];
+  int next = 0;
+  bool ok = false, enabled = true;
+  hipEvent_t doneA = nullptr, doneB = nullptr, doneC = nullptr;  // last reader of dy / dy1 / dyd
+};
+Side g_side;
+
+int side_init() {
+  if (g_side.ok) return 0;
+  const char* e = getenv("ECGMM_SIDE_WGRAD");
+  g_side.enabled = !(e && e[0] == '0');
+  if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess)
+    ECG_FAIL(ECGMM_ERR_LAUNCH, "side stream creation failed");
+  for (int i = 0; i < 32; ++i)
+    if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess)
+      ECG_FAIL(ECGMM_ERR_LAUNCH, "side event creation failed");
+  g_side.ok = true;
+  return 0;
+}
+inline hipEvent_t side_next_ev() { return g_side.ev[g_side.next++ & 31]; }
+// everything enqueued on `main` so far happens-before later work on the side stream
+inline void side_fork(hipStream_t main) {
+  hipEvent_t e = side_next_ev();
+  (void)hipEventRecord(e, main);
+  (void)hipStreamWaitEvent(g_side.s, e, 0);
+}
+inline hipEvent_t side_mark() {
+  hipEvent_t e = side_next_ev();
+  (void)hipEventRecord(e, g_side.s);
+  return e;
+}
+inline void main_wait(hipStream_t main, hipEvent_t& e) {
+  if (e) (void)hipStreamWaitEvent(main, e, 0);
+  e = nullptr;
 }
 
 inline const float* P(const void* const* params, int i) { return (const float*)params[i]; }
@@ -278,9 +327,13 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   if (!ws_fwd || !ws_bwd || ws_bwd_bytes < q.bytes)
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "resnet18 bwd: workspace %zu < %zu", ws_bwd_bytes, q.bytes);
   const int dt = r.d.dtype, N = r.d.N;
+  ECG_TRY(side_init());
+  const bool side = g_side.enabled;
+  hipStream_t ws = side ? g_side.s : s;  // stream of the weight-gradient kernels
 
   for (int st = stage_begin; st < stage_end; ++st) {
     if (st == 0) {
+      g_side.doneA = g_side.doneB = g_side.doneC = nullptr;
       const BlockCfg& last = r.blk[7];
       ECG_TRY(ecg_linear_bwd(dfeat, w.pooled, P(params, r.p_fc), q.dpooled, G(grads, r.p_fc), G(grads, r.p_fc + 1), N,
                              512, r.d.out_dim, q.lin_ws, q.lin_bytes, s));
@@ -297,28 +350,39 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       ConvGeom g1 = make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1);
       ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
       // out = relu(bn2(y2) + identity)
+      main_wait(s, g_side.doneA);  // the previous block's wgrad2 has finished reading q.dy
       ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, nullptr, nullptr, 1, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
                          G(grads, k.p_bn2 + 1), q.dy, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
-      if (G(grads, k.p_conv2))
-        ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, s));
+      if (G(grads, k.p_conv2)) {
+        if (side) side_fork(s);
+        ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, ws));
+        if (side) g_side.doneA = side_mark();
+      }
       ECG_TRY(ecg_conv_igemm(dt, 1, g2, q.dy, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
-      // a1 = relu(bn1(y1))
-      ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1 /* mask recomputed from y1 */, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
-                         G(grads, k.p_bn1 + 1), q.dy, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
-      if (G(grads, k.p_conv1))
-        ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, s));
+      // a1 = relu(bn1(y1)); the mask is recomputed from y1
+      main_wait(s, g_side.doneB);
+      ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
+                         G(grads, k.p_bn1 + 1), q.dy1, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
+      if (G(grads, k.p_conv1)) {
+        if (side) side_fork(s);
+        ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy1, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, ws));
+        if (side) g_side.doneB = side_mark();
+      }
       if (k.down) {
         ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
-        // q.da is free again: use it for the downsample branch's conv-output gradient
+        main_wait(s, g_side.doneC);
         ECG_TRY(ecg_bn_bwd(dt, q.dz, nullptr, nullptr, nullptr, 1, b.yd, b.coefd, P(params, k.p_dbn),
-                           G(grads, k.p_dbn), G(grads, k.p_dbn + 1), q.da, nullptr, nullptr, M, k.cout, q.bn_scratch,
+                           G(grads, k.p_dbn), G(grads, k.p_dbn + 1), q.dyd, nullptr, nullptr, M, k.cout, q.bn_scratch,
                            s));
-        if (G(grads, k.p_dconv))
-          ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.da, G(grads, k.p_dconv), 0, q.wg_ws, q.wg_bytes, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.da, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+        if (G(grads, k.p_dconv)) {
+          if (side) side_fork(s);
+          ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.dyd, G(grads, k.p_dconv), 0, q.wg_ws, q.wg_bytes, ws));
+          if (side) g_side.doneC = side_mark();
+        }
+        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.dyd, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
       } else {
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
       }
     } else if (st == 9) {
       const void* dp0 = q.X[8 & 1];
@@ -330,6 +394,11 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
     } else {
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: stage %d out of range", st);
     }
+  }
+  if (side) {  // join: everything the side stream did is ordered before whatever the caller enqueues next
+    hipEvent_t e = side_next_ev();
+    (void)hipEventRecord(e, g_side.s);
+    (void)hipStreamWaitEvent(s, e, 0);
   }
   return 0;
 }
