@@ -389,8 +389,10 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, r.H1, r.W1, 64, s));
       ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 1), G(grads, 1),
                          G(grads, 2), q.big1, nullptr, nullptr, (long)N * r.H1 * r.W1, 64, q.bn_scratch, s));
-      if (G(grads, 0))
-        ECG_TRY(ecg_stem_wgrad(dt, image, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, 3, r.d.H, r.d.W, 7, s));
+      if (G(grads, 0)) {
+        if (side) side_fork(s);
+        ECG_TRY(ecg_stem_wgrad(dt, image, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, 3, r.d.H, r.d.W, 7, ws));
+      }
     } else {
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: stage %d out of range", st);
     }
