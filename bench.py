@@ -189,37 +189,56 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    roof = None
-    if prof:
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+
+    def collect_roofline(nsteps, note):
         nk = len(PROF_KINDS)
         ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
         rc = lib.ecgmm_prof_collect(nk, ms, fl, by, cnt)
-        lib.ecgmm_prof_enable(0)
         kinds = {PROF_KINDS[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": int(cnt[i])} for i in range(nk)}
-        dom = max(("conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad"), key=lambda k: kinds[k]["ms"])
         # the implicit-GEMM kernel template (fwd + dgrad instantiations) is one kernel class
         ig_ms = kinds["conv_igemm_fwd"]["ms"] + kinds["conv_igemm_dgrad"]["ms"]
         ig_fl = kinds["conv_igemm_fwd"]["flops"] + kinds["conv_igemm_dgrad"]["flops"]
         ig_n = kinds["conv_igemm_fwd"]["launches"] + kinds["conv_igemm_dgrad"]["launches"]
         ig_by = kinds["conv_igemm_fwd"]["bytes"] + kinds["conv_igemm_dgrad"]["bytes"]
+        if rc != 0 or ig_ms <= 0:
+            return None
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (cannot be collected from
         # inside the process): tools/roofline_traffic.py -> profiles/r01_igemm_traffic.json
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
         if args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and os.path.exists(tpath):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"], 1)
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        if rc == 0 and ig_ms > 0:
-            ach = ig_fl / (ig_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad)", "achieved": round(ach, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(ig_by / max(ig_n, 1), 1),
-                    "launches": ig_n, "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4),
-                    "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),
-                    "by_kind": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
-                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
-                                    "launches_per_step": v["launches"] // max(args.steps, 1)} for k, v in kinds.items()},
-                    "slowest_kind": dom}
+        ach = ig_fl / (ig_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad)", "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(ig_by / max(ig_n, 1), 1), "launches": ig_n,
+                "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4), "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),
+                "by_kind": {k: {"ms_per_step": round(v["ms"] / nsteps, 3),
+                                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                "launches_per_step": v["launches"] // max(nsteps, 1)} for k, v in kinds.items()},
+                "note": note}
+
+    roof = roof_serial = None
+    if prof:
+        roof = collect_roofline(args.steps, "HIP events around each launch inside the timed region; kernels of the three "
+                                "encoders and the weight-gradient kernels run CONCURRENTLY on separate streams, so a "
+                                "launch's duration includes the time it shares the GPU with them")
+        # second, untimed pass with the overlap switched off: each kernel alone on the GPU
+        lib.ecgmm_side_wgrad(0)
+        cfg_obj = getattr(model, "config", None)
+        if cfg_obj is not None:
+            cfg_obj.overlap_encoders = False
+        step(); fence()
+        L.check(lib.ecgmm_prof_enable(1), "prof_enable")
+        for _ in range(args.steps):
+            step()
+        fence()
+        roof_serial = collect_roofline(args.steps, "same launches, serialized on one stream (overlap off), untimed extra pass")
+        lib.ecgmm_prof_enable(0)
+        lib.ecgmm_side_wgrad(1)
+        if cfg_obj is not None:
+            cfg_obj.overlap_encoders = True
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -242,6 +261,7 @@ def main():
             "mfma_roofline_frac_whole_step": round(value / world * FLOP_PER_SAMPLE[args.workload] /
                                                    ((PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS) * 1e12), 4),
             "roofline": roof,
+            "roofline_serialized": roof_serial,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -244,6 +244,14 @@ int bn_coef(const R18& r, const float* stats, int rows, int C, long count, const
 
 }  // namespace
 
+// Runtime switch for the side-stream weight-gradient overlap (default on; ECGMM_SIDE_WGRAD=0 disables it
+// at start-up).  bench.py turns it off for its serialized kernel-timing pass.
+extern "C" int ecgmm_side_wgrad(int on) {
+  ECG_TRY(side_init());
+  g_side.enabled = on != 0;
+  return 0;
+}
+
 extern "C" size_t ecgmm_resnet18_fwd_workspace(const ecgmm_resnet18_desc* d) {
   R18 r;
   if (build(d, r)) return 0;

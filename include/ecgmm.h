@@ -66,6 +66,10 @@ int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float* image, co
                             const void* const* params, void* const* grads, void* ws_fwd, void* ws_bwd,
                             size_t ws_bwd_bytes, int stage_begin, int stage_end, void* stream);
 
+/* The ResNet18 backward runs its weight-gradient kernels on a library-owned side stream (forked from /
+ * joined to `stream` with events inside each call).  0 = keep everything on the caller's stream. */
+int ecgmm_side_wgrad(int on);
+
 #define ECGMM_RESNET1D_NPARAMS 52
 #define ECGMM_RESNET1D_NBUFFERS 27
 typedef struct {
