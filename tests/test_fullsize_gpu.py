@@ -1,0 +1,117 @@
+"""BASELINE full sizes (batch 256, 3x224x224 + 5000 + 16, bf16) are too big for the CPU oracle to
+follow in seconds, so they are checked through size-independent properties: run-to-run bitwise
+determinism (no float atomics anywhere on the path), BatchNorm output statistics, linearity of the
+conv kernels, agreement of the concurrent-stream schedule with the serialized one, loss descent."""
+import ctypes as C
+
+import pytest
+import torch
+
+from ecgmm.config import Config
+from ecgmm.hip import functional as HF
+from ecgmm.hip import lib as L
+from ecgmm.hip.functional import ptr, stream
+from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+from ecgmm.optim import FusedAdam
+from ecgmm.parallel import flatten
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B = 256
+
+
+def _model(seed=42, overlap=True):
+    cfg = type("FullCfg", (Config,), {})
+    cfg.compute_dtype, cfg.clinical_input_dim, cfg.overlap_encoders = "bf16", 16, overlap
+    torch.manual_seed(seed)
+    HF.manual_seed(seed)
+    m = ECGMultimodalModel(cfg).to(DEV).train()
+    return m
+
+
+def _batch():
+    g = torch.Generator().manual_seed(7)
+    return (torch.randn(B, 3, 224, 224, generator=g).clamp_(-1, 1).to(DEV), torch.randn(B, 5000, generator=g).to(DEV),
+            torch.randn(B, 16, generator=g).to(DEV), torch.randint(0, 2, (B,), generator=g).to(DEV))
+
+
+def _one_step(model, batch):
+    img, sig, clin, lab = batch
+    out = model(img, sig, clin)
+    loss = HF.cross_entropy(out[3], lab) + 0.1 * out[4]
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), out[3].detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()
+                                                   if p.grad is not None}
+
+
+def test_full_size_step_is_bitwise_deterministic_and_schedule_independent():
+    batch = _batch()
+    runs = []
+    for overlap, side in ((True, 1), (True, 1), (False, 0)):
+        L.check(L.lib().ecgmm_side_wgrad(side))
+        m = _model(overlap=overlap)
+        HF.manual_seed(123)                       # same dropout masks in every run
+        runs.append(_one_step(m, batch))
+        del m
+    L.lib().ecgmm_side_wgrad(1)
+    (l0, y0, g0), (l1, y1, g1), (l2, y2, g2) = runs
+    assert l0 == l1 == l2 and torch.equal(y0, y1) and torch.equal(y0, y2)
+    for k in g0:                                  # concurrent streams vs one stream: identical bits
+        assert torch.equal(g0[k], g1[k]), k
+        assert torch.equal(g0[k], g2[k]), k
+    assert all(torch.isfinite(v).all() for v in g0.values())
+
+
+def test_full_size_training_descends_and_updates_running_stats():
+    m = _model()
+    flatten(m)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    batch = _batch()
+    img, sig, clin, lab = batch
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = m(img, sig, clin)
+        loss = HF.cross_entropy(out[3], lab) + 0.1 * out[4]
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] and all(l == l for l in losses)
+    assert int(m.image_encoder.bn1.num_batches_tracked) == 6
+    assert int(m.signal_encoder.layer3.bn2.num_batches_tracked) == 6
+    assert float(m.image_encoder.layer4[1].bn2.running_var.min()) > 0
+    w = out[5].cpu()
+    assert abs(float(w.sum()) - 1.0) < 1e-5 and out[3].shape == (B, 2)
+
+
+def test_conv_kernels_are_linear_at_full_size():
+    """conv(x1 + x2) == conv(x1) + conv(x2) up to bf16 output rounding, layer1 shape at batch 256."""
+    lib = L.lib()
+    N, H, W, Cn = B, 56, 56, 64
+    d = L.ConvDesc(N, H, W, Cn, Cn, 3, 3, 1, 1, 1)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x1 = (torch.randn(N * H * W * Cn, device=DEV, generator=g)).to(torch.bfloat16)
+    x2 = (torch.randn(N * H * W * Cn, device=DEV, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(Cn * Cn * 9, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    xs = (x1.float() + x2.float()).to(torch.bfloat16)
+    ys = []
+    for x in (x1, x2, xs):
+        y = torch.empty(N * H * W * Cn, device=DEV, dtype=torch.bfloat16)
+        L.check(lib.ecgmm_conv_fwd(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y), None, 0, stream()))
+        ys.append(y.float())
+    torch.cuda.synchronize()
+    # xs itself is rounded to bf16, so compare against that rounding budget
+    err = (ys[2] - (ys[0] + ys[1])).abs()
+    scale = ys[2].abs().mean()
+    assert float(err.mean() / scale) < 2e-2
+    # and BatchNorm partial sums from the epilogue reproduce the column sums of what was stored
+    rows = lib.ecgmm_conv_stats_rows(N * H * W)
+    stats = torch.zeros(rows + 64, 2, Cn, device=DEV)
+    y = torch.empty(N * H * W * Cn, device=DEV, dtype=torch.bfloat16)
+    L.check(lib.ecgmm_conv_fwd(L.BF16, C.byref(d), ptr(xs), ptr(w), None, ptr(y), ptr(stats), 0, stream()))
+    torch.cuda.synchronize()
+    col = y.float().view(-1, Cn)
+    # (stats come from the fp32 accumulators, col from the bf16-stored values: sqrt(N) * 2^-9 * |y| of slack)
+    assert torch.allclose(stats[:rows, 0].sum(0), col.sum(0), rtol=2e-3, atol=20.0)
+    assert torch.allclose(stats[:rows, 1].sum(0), (col * col).sum(0), rtol=5e-3)
