@@ -255,3 +255,60 @@ def test_resnet1d_bf16_no_worse_than_torch_autocast(golden_dir):
 
     keys = [k for k in sd if k.endswith("weight") and k.count(".") >= 1 and sd[k].dim() >= 2]
     _dev_vs_autocast(make_ref, make_net, fill.hash_tensor((6, 1, 2476), 91, 1.5), loss_of, keys)
+
+
+def test_sig12_focal_onecycle_three_steps_vs_reference_golden_g3(golden_dir):
+    """g3: the REFERENCE's 12-lead ResNet1D_SE + FocalLoss + Adam + OneCycleLR (train_signal_12_af.py:238-275),
+    3 steps: same lr / beta1 schedule (OneCycleLR rewrites both every step) and loss trajectory."""
+    from ecgmm.signal_model import FocalLoss
+    g3 = np.load(f"{golden_dir}/g3_sig12_steps.npz")
+    ref = fill.hash_fill_module(O.ResNet1D_SE(12, 2), "sig12.")
+    net = ResNet1D_SE(12, 2, compute_dtype="fp32")
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = _disable_dropout(net).to(DEV).train()
+    x, y = dev(fill.hash_tensor((8, 12, 5000), 555, 1.5)), dev(torch.tensor([0, 1, 1, 0, 1, 0, 0, 1]))
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, steps_per_epoch=4, epochs=30)
+    crit = FocalLoss(alpha=1.0, gamma=2.0)
+    losses = []
+    for i in range(3):
+        assert abs(opt.param_groups[0]["lr"] - g3["lrs"][i]) < 1e-12
+        assert abs(opt.param_groups[0]["betas"][0] - g3["beta1s"][i]) < 1e-9
+        opt.zero_grad()
+        loss = crit(net(x), y)
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, g3["losses"], atol=1e-3), (losses, g3["losses"])
+    net.eval()
+    with torch.no_grad():
+        fin = net(x)
+    assert (fin.cpu() - torch.from_numpy(g3["final_logits"])).abs().max() < 5e-3
+
+
+def test_entry_points_run_on_gpu(tmp_path, monkeypatch):
+    """train.py (frozen encoders, as train.py:35-40), train_image_only.py and train_signal_12_af.py run a tiny
+    synthetic epoch end to end: loaders, freeze, step, validation, checkpoints, test metrics."""
+    import ecgmm.train as T
+    import ecgmm.train_image_only as TI
+    import ecgmm.train_signal_12_af as TS
+    monkeypatch.chdir(tmp_path)
+    cfg = type("Tiny", (Config,), {})
+    cfg.img_height = cfg.img_width = 64
+    cfg.signal_length, cfg.clinical_input_dim = 1000, 16
+    cfg.synthetic_train_size, cfg.synthetic_val_size, cfg.synthetic_test_size, cfg.batch_size = 16, 8, 8, 8
+    cfg.device, cfg.compute_dtype, cfg.checkpoint_dir = "cuda", "bf16", str(tmp_path / "ck")
+    hist, results, ckpt = T.main(cfg, freeze_encoders=True, num_epochs=2, quiet=True)
+    assert len(hist) == 2 and {"best", "last"} <= set(results) and 0.0 <= results["last"]["accuracy"] <= 1.0
+    import os
+    assert {"last.pth", "best.pth", "epoch1.pth"} <= set(os.listdir(ckpt))
+    sd = torch.load(os.path.join(ckpt, "last.pth"), map_location="cpu")
+    assert "image_encoder.layer4.1.bn2.running_var" in sd and "attention_fusion.weights" in sd
+    for k in ("img_height", "img_width", "synthetic_train_size", "synthetic_val_size", "synthetic_test_size", "batch_size",
+              "checkpoint_dir", "device"):
+        monkeypatch.setattr(TI.Config, k, getattr(cfg, k), raising=False)
+    h2, _ = TI.main(num_epochs=1, quiet=True)
+    assert len(h2) == 1 and h2[0][0] == h2[0][0]
+    h3, _ = TS.main(epochs=1, batch_size=8, length=1000, quiet=True)
+    assert len(h3) == 1 and h3[0][0] == h3[0][0]
