@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="multimodal", choices=list(FLOP_PER_SAMPLE))
+    ap.add_argument("--image-hw", default="224x224", help="image size HxW (250x2500 = the reference's full-resolution "
+                    "lead image, dataset_image.py:67-70)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -57,11 +59,12 @@ def build(args, device):
     torch.manual_seed(42)
     HF.manual_seed(42)
     B = args.batch
+    IH, IW = (int(v) for v in args.image_hw.lower().split("x"))
     g = torch.Generator(device="cpu").manual_seed(42 + int(os.environ.get("RANK", 0)))
     if args.workload == "multimodal":
         from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
         model = ECGMultimodalModel(cfg)
-        batch = (torch.randn(B, 3, 224, 224, generator=g).clamp_(-1, 1), torch.randn(B, 5000, generator=g),
+        batch = (torch.randn(B, 3, IH, IW, generator=g).clamp_(-1, 1), torch.randn(B, 5000, generator=g),
                  torch.randn(B, 16, generator=g))
 
         def loss_fn(out, y):   # train.py:69-78
@@ -69,7 +72,7 @@ def build(args, device):
     elif args.workload == "image_only":
         from ecgmm.train_image_only import ImageOnlyClassifier
         model = ImageOnlyClassifier(compute_dtype=args.dtype)
-        batch = (torch.randn(B, 3, 224, 224, generator=g).clamp_(-1, 1),)
+        batch = (torch.randn(B, 3, IH, IW, generator=g).clamp_(-1, 1),)
 
         def loss_fn(out, y):
             return HF.cross_entropy(out, y)
@@ -256,7 +259,7 @@ def main():
                                                    "fwd+bwd+Adam, encoders unfrozen",
                                     "image_only": "image-only ResNet18 (train_image_only.py), fwd+bwd+Adam",
                                     "signal12": "12-lead ResNet1D_SE (train_signal_12_af.py), focal loss, fwd+bwd+Adam"}[args.workload],
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "image_hw": args.image_hw, "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 5)},
             "mfma_roofline_frac_whole_step": round(value / world * FLOP_PER_SAMPLE[args.workload] /
                                                    ((PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS) * 1e12), 4),

@@ -312,3 +312,23 @@ def test_entry_points_run_on_gpu(tmp_path, monkeypatch):
     assert len(h2) == 1 and h2[0][0] == h2[0][0]
     h3, _ = TS.main(epochs=1, batch_size=8, length=1000, quiet=True)
     assert len(h3) == 1 and h3[0][0] == h3[0][0]
+
+
+def test_multimodal_full_resolution_lead_image_train_step_vs_oracle():
+    """the reference's un-resized 250x2500 lead images (dataset_image.py:67-70, README:37) through
+    the same kernels: non-square maps 125x1250 -> 63x625 -> 32x313 -> 16x157 -> 8x79, fp32 parity at B=2."""
+    ref, net = _build_pair("fp32")
+    img = fill.hash_tensor((2, 3, 250, 2500), 808)
+    _, sig, clin, lab = fill.synthetic_batch(2, salt=8)
+    ref.train()
+    out_ref = ref(img, sig, clin)
+    O.multimodal_loss(out_ref, lab).backward()
+    net.train()
+    out = net(dev(img), dev(sig), dev(clin))
+    (HF.cross_entropy(out[3], dev(lab)) + 0.1 * out[4]).backward()
+    torch.cuda.synchronize()
+    assert (out[3].detach().cpu() - out_ref[3].detach()).abs().max() < 1e-3
+    for k in ("image_encoder.conv1.weight", "image_encoder.layer2.0.downsample.0.weight",
+              "image_encoder.layer4.1.conv2.weight", "fusion_classifier.0.weight"):
+        g_ref = dict(ref.named_parameters())[k].grad
+        assert rel_err(dict(net.named_parameters())[k].grad.cpu(), g_ref) < 2e-2, k   # 4M-term fp32 sums, B=2 BatchNorm
