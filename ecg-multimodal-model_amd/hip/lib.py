@@ -90,6 +90,8 @@ SIGNATURES = {
     "ecgmm_dropout_bwd": (i32, [vp, vp, vp, i64, f32, vp]),
     "ecgmm_adam": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),
     "ecgmm_axpby": (i32, [f32, vp, f32, vp, i64, vp]),
+    "ecgmm_signal_preprocess_workspace": (sz, [i32, i32, i32]),
+    "ecgmm_signal_preprocess": (i32, [vp, vp, i32, i32, vp, vp, i32, P(f64), P(f64), P(f64), i32, vp, sz, vp]),
     "ecgmm_prof_enable": (i32, [i32]),
     "ecgmm_prof_collect": (i32, [i32, P(f64), P(f64), P(f64), P(i64)]),
 }

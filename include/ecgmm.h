@@ -211,6 +211,16 @@ int ecgmm_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr
                float weight_decay, int64_t step, float gscale, void* stream);
 int ecgmm_axpby(float a, const float* x, float b, float* y, int64_t n, void* stream);
 
+/* SURVEY 8(f1) -- the step in front of the hot path, on device: per-signal StandardScaler (optional,
+ * per time column) -> moving-average baseline removal (np.convolve(x, ones(w)/w, 'same')) -> IIR
+ * low-pass applied forward-backward exactly as scipy.signal.filtfilt(b, a, x) (odd padding 3*(order+1),
+ * lfilter_zi initial conditions `zi`).  Replaces preprocess_signal: dataset.py:81-95,
+ * train_signal_12_af.py:19-34.  x/out: [S][L] fp32 (S = batch * leads); fp64 arithmetic inside. */
+size_t ecgmm_signal_preprocess_workspace(int S, int L, int order);
+int ecgmm_signal_preprocess(const float* x, float* out, int S, int L, const float* sc_mean, const float* sc_scale,
+                            int window, const double* b, const double* a, const double* zi, int order, void* ws,
+                            size_t ws_bytes, void* stream);
+
 /* Measurement only (no reference counterpart): HIP-event timing of the conv kernels on their launch
  * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad.  collect()
  * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / algorithmic

@@ -7,6 +7,7 @@ TEST INFRASTRUCTURE ONLY.  What it pins:
   g4  reference FocalLoss known answers                                 (imported)
   g5  oracle ECGMultimodalModel (restatement), B=8: eval/train outputs, grads, 3-step Adam losses
   g6  oracle ResNet18 (restatement of torchvision's): per-stage statistics
+  g7  reference preprocess_signal / remove_baseline_drift on [12, 5000] float inputs    (imported)
 and, before writing g1-g3, that oracle.ref_models.ResNet1D_SE is BIT-IDENTICAL to the reference
 class on the same weights/inputs (it is the same sequence of torch ops).
 
@@ -193,6 +194,17 @@ def main():
     g6["train_gnorm_l4_64"] = np.array(r18.layer4[1].conv2.weight.grad.norm().item())
     g6["train_bn1_rm_64"] = npy(r18.bn1.running_mean)
     np.savez_compressed(os.path.join(OUT, "g6_resnet18.npz"), **g6)
+    # ---------------- g7: signal pre-processing, the REFERENCE's own function ---------------------
+    from oracle import preprocess_ref as PR
+    x7 = fill.hash_tensor((12, 5000), 707, 2.0).numpy().astype(np.float64)
+    x7 += np.linspace(-1.5, 2.0, 5000)[None, :] + 0.8 * np.sin(np.arange(5000) / 37.0)[None, :]   # drift + rhythm
+    y_ref = R12.preprocess_signal(x7)                   # train_signal_12_af.py:30-34
+    assert np.array_equal(y_ref, PR.preprocess_signal(x7)), "oracle preprocess_signal differs from the reference's"
+    x7s = x7[:3, :1000]
+    np.savez_compressed(os.path.join(OUT, "g7_preprocess.npz"), x=x7.astype(np.float32),
+                        y=R12.preprocess_signal(x7.astype(np.float32).astype(np.float64)),
+                        y_short=R12.preprocess_signal(x7s.astype(np.float32).astype(np.float64)),
+                        baseline_removed=R12.remove_baseline_drift(x7.astype(np.float32).astype(np.float64)))
     print("goldens written to", OUT)
     for f_ in sorted(os.listdir(OUT)):
         print(f"  {f_}: {os.path.getsize(os.path.join(OUT, f_)) / 1024:.0f} KiB")

@@ -93,3 +93,26 @@ def test_multimodal_oracle_matches_g5(golden_dir):
         out = model(img, sig, clin)
     assert torch.allclose(out[3], torch.from_numpy(g5["eval.fusion_logits"]), atol=2e-5)
     assert abs(out[4].item() - float(g5["eval.var_loss"])) < 1e-5
+
+
+def test_preprocess_oracle_and_native_filter_design(golden_dir):
+    """g7 comes from the reference's own preprocess_signal; the host-side filter design (no scipy at run time)
+    reproduces scipy's butter / lfilter_zi and the SURVEY 8c known answer."""
+    from oracle import preprocess_ref as PR
+    from ecgmm.preprocess import butter_lowpass, lfilter_zi
+    from scipy.signal import butter, lfilter_zi as sp_zi
+    g7 = np.load(f"{golden_dir}/g7_preprocess.npz")
+    x = g7["x"].astype(np.float64)
+    assert np.allclose(PR.preprocess_signal(x), g7["y"], rtol=0, atol=1e-12)
+    assert np.allclose(PR.remove_baseline_drift(x), g7["baseline_removed"], rtol=0, atol=1e-12)
+    b, a = butter_lowpass(5, 0.1)
+    kat_b = [5.97957804e-05, 2.98978902e-04, 5.97957804e-04, 5.97957804e-04, 2.98978902e-04, 5.97957804e-05]
+    kat_a = [1, -3.98454312, 6.43486709, -5.25361517, 2.16513291, -0.35992825]
+    assert np.allclose(b, kat_b, rtol=1e-8) and np.allclose(a, kat_a, rtol=1e-8)
+    bs, as_ = butter(5, 0.1)
+    assert np.allclose(b, bs, rtol=1e-13, atol=0) and np.allclose(a, as_, rtol=1e-13, atol=0)
+    assert np.allclose(lfilter_zi(b, a), sp_zi(bs, as_), rtol=1e-9)
+    for order, wn in ((3, 0.2), (7, 0.05), (1, 0.5)):
+        b2, a2 = butter_lowpass(order, wn)
+        bs2, as2 = butter(order, wn)
+        assert np.allclose(b2, bs2, rtol=1e-10) and np.allclose(a2, as2, rtol=1e-10)
