@@ -3,9 +3,10 @@
 //   -> 5th-order Butterworth low-pass applied forward-backward (scipy.signal.filtfilt, odd padding of
 //   3*(order+1) samples, steady-state initial conditions)          dataset.py:66-71,81-95;
 //   train_signal_12_af.py:19-34 (same functions over [leads, time]).
-// One lane = one signal (the IIR recurrence is sequential in time); intermediates live transposed
-// ([time][signal]) in a caller-owned fp64 workspace so every step of the recurrence is a coalesced
-// access across the wave.  All arithmetic in fp64 (the reference computes in float64), output fp32
+// Two kernels: the LDS-resident chunk-parallel one below (one wave per signal, used whenever the padded
+// record fits a CU's 160 KiB LDS -- every ECG length the reference uses), and a one-lane-per-signal
+// kernel whose intermediates live transposed ([time][signal]) in a caller-owned fp64 workspace, for
+// longer records.  All arithmetic in fp64 (the reference computes in float64), output fp32
 // (the reference casts with torch.tensor(..., dtype=torch.float)).
 #include "ops.h"
 
@@ -74,6 +75,142 @@ __global__ __launch_bounds__(64) void signal_preprocess_kernel(PreParams p) {
   }
 }
 
+// ---- LDS-resident variant: one wave per signal, the whole padded signal in LDS (fp64) ----
+// The IIR recurrence z' = A z + B x is linear, so the time axis is cut into 64 chunks of C samples:
+//   (1) every lane filters its chunk from a ZERO state and keeps only the final state s_t;
+//   (2) lane 0 chains the true chunk-entry states  z_{t+1} = A^C z_t + s_t  (A^C built once by lanes
+//       0..N-1 running C zero-input steps from the unit states);
+//   (3) every lane re-filters its chunk from its true entry state, writing y in place.
+// C is forced odd so the 64 lanes' chunk cursors (stride C doubles) fall in distinct LDS banks.
+template <int N>
+__global__ __launch_bounds__(64) void signal_preprocess_lds_kernel(PreParams p) {
+  extern __shared__ double sm[];
+  constexpr int T = 64, PAD = 3 * (N + 1);
+  const int L = p.L, M = p.window, E = L + 2 * PAD;
+  const int lane = threadIdx.x, s = blockIdx.x;
+  double* A = sm;            // [L]     scaled input
+  double* B = sm + L;        // [E]     odd-extended, baseline-removed signal; filtered in place
+  double* st = B + E;        // [T][8]  chunk states
+  double* Mx = st + T * 8;   // [8][8]  A^C, row-major
+  double b[N + 1], a[N + 1];
+#pragma unroll
+  for (int i = 0; i <= N; ++i) { b[i] = p.b[i]; a[i] = p.a[i]; }
+
+  const float* xr = p.x + (size_t)s * L;
+  for (int t = lane; t < L; t += T) {
+    double v = (double)xr[t];
+    if (p.sc_mean) v = (v - (double)p.sc_mean[t]) / (double)p.sc_scale[t];
+    A[t] = v;
+  }
+  const int C = ((E + T - 1) / T) | 1;
+  if (lane < N) {  // column `lane` of A^C
+    double z[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = i == lane ? 1.0 : 0.0;
+    for (int k = 0; k < C; ++k) {
+      const double y = z[0];
+#pragma unroll
+      for (int i = 0; i < N - 1; ++i) z[i] = z[i + 1] - a[i + 1] * y;
+      z[N - 1] = -a[N] * y;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) Mx[i * 8 + lane] = z[i];
+  }
+  __syncthreads();
+  {  // moving-average baseline, np.convolve(x, ones(M)/M, 'same'): mean over [i - bk, i + fw], zero outside
+    const int fw = (M - 1) / 2, bk = M - 1 - fw;
+    const int Cm = ((L + T - 1) / T) | 1;
+    const int i0 = lane * Cm, i1 = min(L, i0 + Cm);
+    if (i0 < L) {
+      double run = 0.0;
+      for (int j = max(0, i0 - bk); j <= min(L - 1, i0 + fw); ++j) run += A[j];
+      for (int i = i0; i < i1; ++i) {
+        B[PAD + i] = A[i] - run / (double)M;
+        const int add = i + fw + 1, sub = i - bk;
+        if (add < L) run += A[add];
+        if (sub >= 0) run -= A[sub];
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < PAD) {  // odd extension about both ends
+    B[lane] = 2.0 * B[PAD] - B[PAD + (PAD - lane)];
+    B[PAD + L + lane] = 2.0 * B[PAD + L - 1] - B[PAD + L - 2 - lane];
+  }
+  __syncthreads();
+
+  const int k0 = lane * C, k1 = min(E, k0 + C);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    auto at = [&](int k) -> double& { return B[pass ? E - 1 - k : k]; };
+    double z[N];
+    if (k1 - k0 == C) {  // a full chunk hands a state on
+#pragma unroll
+      for (int i = 0; i < N; ++i) z[i] = 0.0;
+      for (int k = k0; k < k1; ++k) {
+        const double e = at(k);
+        const double y = b[0] * e + z[0];
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) z[i] = b[i + 1] * e + z[i + 1] - a[i + 1] * y;
+        z[N - 1] = b[N] * e - a[N] * y;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) st[lane * 8 + i] = z[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      const double e0 = at(0);
+      double m[N][N];
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[i][j] = Mx[i * 8 + j];
+#pragma unroll
+      for (int i = 0; i < N; ++i) z[i] = p.zi[i] * e0;
+      const int nchunks = (E + C - 1) / C;
+      for (int t = 0; t < nchunks; ++t) {
+        double sv[N], zn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { sv[i] = st[t * 8 + i]; st[t * 8 + i] = z[i]; }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          double acc = sv[i];
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc += m[i][j] * z[j];
+          zn[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) z[i] = zn[i];
+      }
+    }
+    __syncthreads();
+    if (k0 < E) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) z[i] = st[lane * 8 + i];
+      for (int k = k0; k < k1; ++k) {
+        double& r = at(k);
+        const double e = r;
+        const double y = b[0] * e + z[0];
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) z[i] = b[i + 1] * e + z[i + 1] - a[i + 1] * y;
+        z[N - 1] = b[N] * e - a[N] * y;
+        r = y;
+      }
+    }
+    __syncthreads();
+  }
+  float* orow = p.out + (size_t)s * L;
+  for (int t = lane; t < L; t += T) orow[t] = (float)B[PAD + t];
+}
+
+template <int N>
+int launch_lds(const PreParams& p, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)signal_preprocess_lds_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  hipLaunchKernelGGL(signal_preprocess_lds_kernel<N>, dim3(p.S), dim3(64), lds, st, p);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" size_t ecgmm_signal_preprocess_workspace(int S, int L, int order) {
@@ -97,7 +234,23 @@ extern "C" int ecgmm_signal_preprocess(const float* x, float* out, int S, int L,
   p.S = S; p.L = L; p.window = window; p.order = order;
   for (int i = 0; i <= order; ++i) { p.b[i] = b[i]; p.a[i] = a[i]; }
   for (int i = 0; i < order; ++i) p.zi[i] = zi[i];
-  hipLaunchKernelGGL(signal_preprocess_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, (hipStream_t)stream, p);
+  // LDS-resident chunk-parallel kernel whenever one padded signal (+ the scaled copy) fits one CU's LDS;
+  // longer records take the one-lane-per-signal kernel over the global workspace.
+  const size_t lds = ((size_t)L + L + 6 * (order + 1) + 64 * 8 + 64) * sizeof(double);
+  if (lds <= 160 * 1024) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (order) {
+      case 1: launch_lds<1>(p, lds, st); break;
+      case 2: launch_lds<2>(p, lds, st); break;
+      case 3: launch_lds<3>(p, lds, st); break;
+      case 4: launch_lds<4>(p, lds, st); break;
+      case 5: launch_lds<5>(p, lds, st); break;
+      case 6: launch_lds<6>(p, lds, st); break;
+      default: launch_lds<7>(p, lds, st); break;
+    }
+  } else {
+    hipLaunchKernelGGL(signal_preprocess_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, (hipStream_t)stream, p);
+  }
   ECG_CHECK_LAUNCH("signal_preprocess");
   return 0;
 }

@@ -39,6 +39,18 @@ def test_matches_scipy_restatement_live(shape):
     assert np.abs(y.cpu().numpy().astype(np.float64) - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("shape,order,cutoff", [((4, 12000), 5, 0.05), ((6, 3000), 3, 0.1), ((6, 999), 7, 0.08),
+                                                ((2, 4000), 1, 0.2), ((3, 20000), 2, 0.05)])
+def test_other_orders_and_long_records(shape, order, cutoff):
+    """records too long for one CU's LDS take the workspace kernel; every supported order has its own instantiation"""
+    x = fill.hash_tensor(shape, 313, 1.0).numpy().astype(np.float32)
+    x += np.sin(np.arange(shape[-1]) / 37.0).astype(np.float32)
+    ref = PR.lowpass_filter(PR.remove_baseline_drift(x.astype(np.float64)), cutoff=cutoff, order=order)
+    y = PP.preprocess_signal(torch.from_numpy(x).to(DEV), cutoff=cutoff, order=order)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy().astype(np.float64) - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
+
+
 def test_rejects_bad_arguments():
     x = torch.zeros(2, 100, device=DEV)
     with pytest.raises(RuntimeError, match="window"):
