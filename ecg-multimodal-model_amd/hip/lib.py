@@ -92,6 +92,9 @@ SIGNATURES = {
     "ecgmm_axpby": (i32, [f32, vp, f32, vp, i64, vp]),
     "ecgmm_signal_preprocess_workspace": (sz, [i32, i32, i32]),
     "ecgmm_signal_preprocess": (i32, [vp, vp, i32, i32, vp, vp, i32, P(f64), P(f64), P(f64), i32, vp, sz, vp]),
+    "ecgmm_image_resize_tables_bytes": (sz, [i32, i32, i32, i32]),
+    "ecgmm_image_resize_tables": (i32, [i32, i32, i32, i32, vp, sz]),
+    "ecgmm_image_transform": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, P(f32), P(f32), vp]),
     "ecgmm_prof_enable": (i32, [i32]),
     "ecgmm_prof_collect": (i32, [i32, P(f64), P(f64), P(f64), P(i64)]),
 }

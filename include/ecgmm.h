@@ -221,6 +221,18 @@ int ecgmm_signal_preprocess(const float* x, float* out, int S, int L, const floa
                             int window, const double* b, const double* a, const double* zi, int order, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* SURVEY 8(f1), image half: Resize((OH, OW)) -> ToTensor -> Normalize(mean, std) of decoded RGB pictures
+ * (dataset.py:61,119-123; train_image_only.py:58-62; dataset_image.py:67-70 when OH==H && OW==W).
+ * torchvision hands a PIL picture to Pillow's antialiased BILINEAR resample (8 bpc, two passes, 22-bit
+ * fixed-point coefficients, uint8 intermediate); the result is bit-identical to Pillow followed by
+ * float32 x/255 and (x-mean)/std.  img: uint8 [B][H][W][3] on the device; out: fp32 [B][3][OH][OW].
+ * The coefficient table is built on the host (tables_bytes / tables) and copied to the device by the
+ * caller once per (H, W, OH, OW); it is not needed (may be NULL) when no resize takes place. */
+size_t ecgmm_image_resize_tables_bytes(int H, int W, int OH, int OW);
+int ecgmm_image_resize_tables(int H, int W, int OH, int OW, void* host_tables, size_t bytes);
+int ecgmm_image_transform(const void* img, float* out, int B, int H, int W, int OH, int OW, const void* dev_tables,
+                          size_t table_bytes, const float* mean3, const float* std3, void* stream);
+
 /* Measurement only (no reference counterpart): HIP-event timing of the conv kernels on their launch
  * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad.  collect()
  * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / algorithmic

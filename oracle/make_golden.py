@@ -8,6 +8,9 @@ TEST INFRASTRUCTURE ONLY.  What it pins:
   g5  oracle ECGMultimodalModel (restatement), B=8: eval/train outputs, grads, 3-step Adam losses
   g6  oracle ResNet18 (restatement of torchvision's): per-stage statistics
   g7  reference preprocess_signal / remove_baseline_drift on [12, 5000] float inputs    (imported)
+  g8  the image transform: Pillow's own BILINEAR resize (the arithmetic torchvision's Resize runs on a PIL
+      picture; torchvision itself is absent here and unpinned in the reference) of formula pictures,
+      + float32 ToTensor/Normalize; `python oracle/make_golden.py g8` regenerates only this file
 and, before writing g1-g3, that oracle.ref_models.ResNet1D_SE is BIT-IDENTICAL to the reference
 class on the same weights/inputs (it is the same sequence of torch ops).
 
@@ -34,7 +37,32 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+G8_CASES = [(250, 2500, 224, 224), (300, 400, 224, 224), (100, 120, 224, 224), (37, 53, 16, 20), (500, 224, 224, 224)]
+
+
+def g8_image():
+    from PIL import Image
+    from oracle import image_ref as IR
+    g8 = {"cases": np.array(G8_CASES, np.int32)}
+    for i, (h, w, oh, ow) in enumerate(G8_CASES):
+        img = IR.synthetic_ecg_picture(h, w, 31 + i)
+        pil = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BILINEAR))   # == transforms.Resize((oh, ow))
+        assert np.array_equal(pil, IR.resize_bilinear_u8(img, oh, ow)), f"oracle resize differs from Pillow on case {i}"
+        g8[f"resized_{i}"] = pil
+        g8[f"sha_in_{i}"] = np.frombuffer(__import__("hashlib").sha256(img.tobytes()).digest(), np.uint8)
+    # ToTensor + Normalize exactly as torch does it in float32 (checked against torch ops here)
+    u = np.arange(256, dtype=np.uint8)
+    t = (torch.from_numpy(u).to(torch.float32).div(255) - 0.5) / 0.5
+    assert np.array_equal(t.numpy(), IR.to_tensor_normalize(u.reshape(16, 16, 1).repeat(3, 2))[0].reshape(-1))
+    g8["normalize_lut"] = t.numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_image.npz"), **g8)
+
+
 def main():
+    if sys.argv[1:] == ["g8"]:
+        g8_image()
+        print("g8 written")
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     sys.path.insert(0, REF)
@@ -205,6 +233,7 @@ def main():
                         y=R12.preprocess_signal(x7.astype(np.float32).astype(np.float64)),
                         y_short=R12.preprocess_signal(x7s.astype(np.float32).astype(np.float64)),
                         baseline_removed=R12.remove_baseline_drift(x7.astype(np.float32).astype(np.float64)))
+    g8_image()
     print("goldens written to", OUT)
     for f_ in sorted(os.listdir(OUT)):
         print(f"  {f_}: {os.path.getsize(os.path.join(OUT, f_)) / 1024:.0f} KiB")

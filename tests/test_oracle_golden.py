@@ -116,3 +116,38 @@ def test_preprocess_oracle_and_native_filter_design(golden_dir):
         b2, a2 = butter_lowpass(order, wn)
         bs2, as2 = butter(order, wn)
         assert np.allclose(b2, bs2, rtol=1e-10) and np.allclose(a2, as2, rtol=1e-10)
+
+
+def test_image_transform_oracle_matches_pillow_golden(golden_dir):
+    """g8 holds Pillow's own BILINEAR outputs; the restatement reproduces them bit for bit, and (Pillow being
+    installed wherever the tests run) again live on a shape outside the fixture."""
+    import hashlib
+    from oracle import image_ref as IR
+    g8 = np.load(f"{golden_dir}/g8_image.npz")
+    for i, (h, w, oh, ow) in enumerate(g8["cases"]):
+        img = IR.synthetic_ecg_picture(int(h), int(w), 31 + i)
+        assert hashlib.sha256(img.tobytes()).digest() == g8[f"sha_in_{i}"].tobytes()   # formula picture is stable
+        assert np.array_equal(IR.resize_bilinear_u8(img, int(oh), int(ow)), g8[f"resized_{i}"])
+    lut = IR.to_tensor_normalize(np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, 2))[1].reshape(-1)
+    assert np.array_equal(lut, g8["normalize_lut"])
+    from PIL import Image
+    img = IR.synthetic_ecg_picture(91, 333, 5)
+    assert np.array_equal(np.asarray(Image.fromarray(img, "RGB").resize((64, 48), Image.BILINEAR)),
+                          IR.resize_bilinear_u8(img, 48, 64))
+
+
+def test_library_resize_tables_match_the_oracle_coefficients():
+    """host-side half of the C ABI (no GPU needed): the coefficient table the kernel consumes"""
+    import ctypes as C
+    from ecgmm.hip import lib as L
+    from oracle import image_ref as IR
+    lib = L.lib()
+    for (h, w, oh, ow) in [(250, 2500, 224, 224), (100, 120, 224, 224), (37, 53, 16, 20)]:
+        nb = lib.ecgmm_image_resize_tables_bytes(h, w, oh, ow)
+        buf = np.zeros(nb // 4, np.int32)
+        assert lib.ecgmm_image_resize_tables(h, w, oh, ow, buf.ctypes.data_as(C.c_void_p), nb) == 0
+        hb, hk = IR._coeffs(w, ow)
+        vb, vk = IR._coeffs(h, oh)
+        want = np.concatenate([hb.reshape(-1), hk.reshape(-1), vb.reshape(-1), vk.reshape(-1)])
+        assert np.array_equal(buf, want)
+        assert lib.ecgmm_image_resize_tables(h, w, oh, ow, buf.ctypes.data_as(C.c_void_p), nb - 4) != 0
