@@ -23,7 +23,8 @@ def test_matches_pillow_golden_bit_for_bit(golden_dir):
 
 @pytest.mark.parametrize("case", [(5, 250, 2500, 224, 224), (3, 224, 224, 224, 224), (2, 250, 2500, 250, 2500),
                                   (4, 250, 2500, 125, 1250), (3, 64, 48, 224, 224), (2, 7, 9, 5, 4),
-                                  (1, 1000, 31, 10, 30), (2, 300, 5000, 224, 224)])
+                                  (1, 1000, 31, 10, 30), (2, 300, 5000, 224, 224), (2, 40, 6000, 20, 100),
+                                  (2, 100, 5461, 50, 224), (3, 30, 40, 30, 64)])
 def test_batches_and_other_shapes_vs_oracle(case):
     B, h, w, oh, ow = case
     imgs = np.stack([IR.synthetic_ecg_picture(h, w, 70 + b) for b in range(B)])
