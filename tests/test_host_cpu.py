@@ -59,7 +59,7 @@ def test_product_modules_have_no_cpu_path():
 
 
 def test_datasets():
-    ds = ECGMultimodalDataset(5, Config)
+    ds = ECGMultimodalDataset.synthetic(5, Config)
     img, sig, clin, lab, idx = ds[3]
     assert img.shape == (3, 224, 224) and img.dtype == torch.float32 and img.abs().max() <= 1
     assert sig.shape == (5000,) and clin.shape == (24,) and lab.dtype == torch.int64 and idx == 3
@@ -70,6 +70,28 @@ def test_datasets():
     assert [t.shape[0] for t in batch] == [8, 8, 8, 8] and len(index) == 8
     d = ECGDataset(np.ones((3, 7)), [0, 1, 0])
     assert len(d) == 3 and d[1][0].dtype == torch.float32 and d[1][1].dtype == torch.int64
+
+
+def test_file_datasets_follow_the_reference_tables(tmp_path):
+    """real-file path, host half: filtering, index intersection, stratified split, scalers, raw items"""
+    from ecgmm import dataset as D
+    from oracle import dataset_ref as DR
+    ids = DR.write_tiny_dataset(str(tmp_path), n=40, sig_len=600, hw=(50, 500))
+    cfg = type("Files", (Config,), {"synthetic": False, "data_dir": str(tmp_path), "image_dir": str(tmp_path / "images"),
+                                    "ecg_csv": str(tmp_path / "ecg_signals.csv"), "label_file": str(tmp_path / "labels.xlsx"),
+                                    "clinical_file": str(tmp_path / "clinical.csv"), "batch_size": 4})
+    labels_df, ecg, clin = D.load_tables(cfg)                       # labels.xlsx -> labels.csv fallback (no openpyxl here)
+    assert len(labels_df) == 38 and "ECG" not in clin.columns       # one Borderline, one subject without a picture
+    assert set(labels_df["label"]) == {0, 1} and list(ecg.index) == list(labels_df["index"])
+    sets, ecg_scaler, clin_scaler = D.build_file_datasets(cfg)
+    assert [len(s) for s in sets] == [30, 4, 4]
+    assert not (set(sets[0].labels_df["index"]) & set(sets[2].labels_df["index"]))
+    tr_rows = ecg.loc[ecg.index.isin(sets[0].labels_df["index"])].values
+    assert np.allclose(ecg_scaler.mean_, tr_rows.mean(0)) and np.allclose(ecg_scaler.scale_, tr_rows.std(0))
+    pic, sig, c, lab, index = sets[1][2]
+    assert pic.dtype == torch.uint8 and pic.shape == (50, 500, 3) and sig.shape == (600,) and sig.dtype == torch.float32
+    assert c.shape == (2,) and lab.dtype == torch.int64 and index in ids
+    assert np.allclose(sig.numpy(), ecg.loc[index].values.astype(np.float32))
 
 
 def _free_port():
