@@ -121,7 +121,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       (void*)wpk, 0, (int)((size_t)p.Cd * p.R * p.S * p.Cs * sizeof(T)), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFFFu;
-  int nbh[4], hb[4], wb[4];
+  // Per gathered row: source-space coordinates (hq, wq) and byte offset (offb) of filter tap (0,0); tap
+  // (g_r, g_s) then sits at hq + SGN*g_r, wq + SGN*g_s, i.e. a wave-uniform byte delta away.
+  constexpr int SGN = MODE == 0 ? 1 : -1;
+  const unsigned pix_bytes = (unsigned)p.Cs * (unsigned)sizeof(T);
+  int hq[4], wq[4];
+  unsigned offb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int pix = m0 + wave * 32 + i * 8 + lrow8;
@@ -134,20 +139,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       hd = hd * 2 + ph;
       wd = wd * 2 + pw;
     }
-    nbh[i] = (n - n_first) * p.Hs;
     if (MODE == 0) {
-      hb[i] = hd * p.stride - p.pad_h;
-      wb[i] = wd * p.stride - p.pad_w;
+      hq[i] = hd * p.stride - p.pad_h;
+      wq[i] = wd * p.stride - p.pad_w;
+    } else if (ST == 2) {  // (hd + pad - r0, wd + pad - s0 are even by construction of the parity class)
+      hq[i] = (hd + p.pad_h - r0) >> 1;
+      wq[i] = (wd + p.pad_w - s0) >> 1;
     } else {
-      hb[i] = hd + p.pad_h;
-      wb[i] = wd + p.pad_w;
+      hq[i] = hd + p.pad_h;
+      wq[i] = wd + p.pad_w;
     }
-    if (!rok) hb[i] = MODE == 0 ? -(1 << 28) : (1 << 28);  // every tap of a padding row falls out of range
+    offb[i] = (unsigned)(((n - n_first) * p.Hs + hq[i]) * p.Ws + wq[i]) * pix_bytes;
+    if (!rok) hq[i] = 1 << 28;  // every tap of a padding row falls out of range
   }
   const int RS = p.R * p.S;
   const int cpt = (p.Cs + KBE - 1) / KBE;  // stages per tap
   const int nk = Rc * Sc * cpt;
-  const unsigned pix_bytes = (unsigned)p.Cs * (unsigned)sizeof(T);
   unsigned wrow[NWV];
 #pragma unroll
   for (int i = 0; i < NWV; ++i) {
@@ -162,26 +169,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     const int r = r0 + g_r * TSTEP, s = s0 + g_s * TSTEP;
     const int ch = g_cc * KBE + lchunk * VEC;
     const unsigned chb = ch < p.Cs ? (unsigned)ch * (unsigned)sizeof(T) : OOB;
+    const unsigned tapd = (unsigned)(SGN * (g_r * p.Ws + g_s)) * pix_bytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int hs, ws;
-      bool ok = true;
-      if (MODE == 0) {
-        hs = hb[i] + r;
-        ws = wb[i] + s;
-      } else {
-        int th = hb[i] - r, tw = wb[i] - s;
-        if (ST == 2) {  // (th, tw are even by construction of the parity class)
-          hs = th >> 1;
-          ws = tw >> 1;
-        } else {
-          hs = th;
-          ws = tw;
-        }
-      }
-      ok = ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-      unsigned off = (unsigned)((nbh[i] + hs) * p.Ws + ws) * pix_bytes + chb;
-      dma16(rs_src, sX + (wv * 4 + i) * 1024, (ok && chb != OOB) ? off : OOB);
+      const bool ok = (unsigned)(hq[i] + SGN * g_r) < (unsigned)p.Hs && (unsigned)(wq[i] + SGN * g_s) < (unsigned)p.Ws;
+      dma16(rs_src, sX + (wv * 4 + i) * 1024, (ok && chb != OOB) ? offb[i] + tapd + chb : OOB);
     }
     const unsigned tapb = (unsigned)(r * p.S + s) * pix_bytes + chb;
 #pragma unroll
