@@ -60,23 +60,40 @@ __device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patc
 
 // Split form for software pipelining: fetch the NEXT tile's patch into registers while the current
 // tile computes, write it to LDS after the barrier.  NPRE * 256 >= Cin * PH * PWS (checked on the host).
+// Which patch element a thread fetches does not depend on the tile, so its image-relative offset and its
+// (row, col) inside the patch are decoded ONCE per workgroup (StemPatchIdx); per tile only the origin moves
+// (the decode is ~30 VALU with quarter-rate mul_hi per element: it was most of the kernel's VALU time).
 constexpr int NPRE = 16;
+struct StemPatchIdx {
+  int rel[NPRE];  // (c * H + ph) * W + pw
+  int hw[NPRE];   // ph << 16 | pw; 0x7fff7fff for slots outside the patch
+};
 template <int R>
-__device__ __forceinline__ void stem_fetch_patch(const StemParams& p, float (&pre)[NPRE], int n, int oh0, int ow0) {
+__device__ __forceinline__ void stem_patch_idx(const StemParams& p, StemPatchIdx& ix) {
   constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS;
   const int total = p.Cin * PH * PWS;
-  const float* xin = p.x + (size_t)n * p.Cin * p.H * p.W;
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) {
     const int i = threadIdx.x + 256 * k;
     int pw = i % PWS;
     int t = i / PWS;
     int ph = t % PH, c = t / PH;
-    int ih = oh0 * 2 - p.pad_h + ph, iw = ow0 * 2 - 3 + pw;
-    float v = 0.f;
-    if (i < total && pw < PW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-      v = xin[((size_t)c * p.H + ih) * p.W + iw];
-    pre[k] = v;
+    const bool in = i < total && pw < PW;
+    ix.rel[k] = in ? (c * p.H + ph) * p.W + pw : 0;
+    ix.hw[k] = in ? (ph << 16 | pw) : 0x7fff7fff;
+  }
+}
+template <int R>
+__device__ __forceinline__ void stem_fetch_patch(const StemParams& p, const StemPatchIdx& ix, float (&pre)[NPRE], int n,
+                                                 int oh0, int ow0) {
+  const int ih0 = oh0 * 2 - p.pad_h, iw0 = ow0 * 2 - 3;
+  // (may point in front of the image; only dereferenced for in-range elements)
+  const float* base = p.x + ((size_t)n * p.Cin * p.H + ih0) * (ptrdiff_t)p.W + iw0;
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int ph = ix.hw[k] >> 16, pw = ix.hw[k] & 0xffff;
+    const bool ok = (unsigned)(ih0 + ph) < (unsigned)p.H && (unsigned)(iw0 + pw) < (unsigned)p.W;
+    pre[k] = ok ? base[ix.rel[k]] : 0.f;
   }
 }
 template <int R>
@@ -122,11 +139,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }
   const int ntiles = p.N * p.tiles_h * p.tiles_w;
   float pre[NPRE];
+  StemPatchIdx pix;
+  stem_patch_idx<R>(p, pix);
   {
     int n_, oh_, ow_;
     if ((int)blockIdx.x < ntiles) {
       stem_tile_origin(p, blockIdx.x, TH, TW, n_, oh_, ow_);
-      stem_fetch_patch<R>(p, pre, n_, oh_, ow_);
+      stem_fetch_patch<R>(p, pix, pre, n_, oh_, ow_);
     }
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   if (tile + (int)gridDim.x < ntiles) {  // next tile's patch streams in underneath this tile's MFMAs
     int n_, oh_, ow_;
     stem_tile_origin(p, tile + gridDim.x, TH, TW, n_, oh_, ow_);
-    stem_fetch_patch<R>(p, pre, n_, oh_, ow_);
+    stem_fetch_patch<R>(p, pix, pre, n_, oh_, ow_);
   }
 
   f32x4 acc[4][2];
@@ -305,6 +324,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   constexpr int NDY = 128 * CH / 256;           // dy vectors per thread per tile (4 bf16 / 8 f32)
   float pre[NPRE];
   u32x4 pdy[NDY];
+  StemPatchIdx pix;
+  stem_patch_idx<R>(p, pix);
   auto fetch = [&](int tile) {
     int n, oh0, ow0;
     stem_tile_origin(p, tile, TH, TW, n, oh0, ow0);
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
                                             chunk * (16 / (int)sizeof(T)));
       pdy[k] = v;
     }
-    stem_fetch_patch<R>(p, pre, n, oh0, ow0);
+    stem_fetch_patch<R>(p, pix, pre, n, oh0, ow0);
   };
   if (t_begin < t_end) fetch(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {

@@ -388,13 +388,25 @@ __global__ __launch_bounds__(EW_THREADS) void bnrelu_maxpool_kernel(const T* __r
       }
     }
     st16(out + pix * C + c0, pack16<T>(best));
-    unsigned char* ip = idx + pix * C + c0;
+    // the VEC argmax bytes of this chunk go out as one 8-B (bf16) / 4-B (f32) store
+    unsigned pk[VEC / 4];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) ip[j] = (unsigned char)bi[j];
+    for (int q = 0; q < VEC / 4; ++q)
+      pk[q] = (unsigned)bi[4 * q] | ((unsigned)bi[4 * q + 1] << 8) | ((unsigned)bi[4 * q + 2] << 16) |
+              ((unsigned)bi[4 * q + 3] << 24);
+    unsigned* ip = reinterpret_cast<unsigned*>(idx + pix * C + c0);
+    if constexpr (VEC == 8) *reinterpret_cast<uint2*>(ip) = make_uint2(pk[0], pk[1]);
+    else ip[0] = pk[0];
   }
 }
 
 // dz[n,h,w,c] = sum over the <=4 windows containing (h,w): dp[win] * [idx[win]==tap] * [p[win] > 0]
+// One thread = a 2x2 block of input pixels (h = 2k, 2k+1; w = 2m, 2m+1) x one 16-B channel chunk.  The block
+// touches exactly the windows (k, k+1) x (m, m+1), each loaded once (dp, pooled, argmax bytes) with all loads
+// issued up front; which tap of which window feeds which pixel is a compile-time table:
+//   (2k,2m): w00 tap 4 | (2k,2m+1): w00 tap 5, w01 tap 3 | (2k+1,2m): w00 tap 7, w10 tap 1
+//   (2k+1,2m+1): w00 tap 8, w01 tap 6, w10 tap 2, w11 tap 0          (w_ab = window (k+a, m+b))
+// (a thread per pixel re-loaded every window 2.25x on average and diverged on the 1/2/4-window cases)
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_relu_bwd_kernel(const T* __restrict__ dp,
                                                                       const T* __restrict__ pooled,
@@ -403,37 +415,57 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_relu_bwd_kernel(const T* _
                                                                       int OH, int OW) {
   constexpr int VEC = Elem<T>::VEC;
   const int cpr = C / VEC;
-  long total = (long)N * H * W * cpr;
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  long total = (long)N * H2 * W2 * cpr;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int chunk = (int)(i % cpr);
-    long pix = i / cpr;
-    int w = (int)(pix % W);
-    long t = pix / W;
-    int h = (int)(t % H), n = (int)(t / H);
+    long blk = i / cpr;
+    int m = (int)(blk % W2);
+    long t = blk / W2;
+    int k = (int)(t % H2), n = (int)(t / H2);
     int c0 = chunk * VEC;
-    float acc[VEC];
+    float d[4][VEC], pv[4][VEC];
+    unsigned pk[4][2];
+    bool wok[4];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;  // windows with oh*2-1 <= h <= oh*2+1
-    int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
-    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-      if (oh >= OH) continue;
-      int kh = h - (oh * 2 - 1);
-      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        if (ow >= OW) continue;
-        int kw = w - (ow * 2 - 1);
-        int tap = kh * 3 + kw;
-        size_t o = (((size_t)n * OH + oh) * OW + ow) * C + c0;
-        float d[VEC], pv[VEC];
-        unpack16<T>(ld16(dp + o), d);
-        unpack16<T>(ld16(pooled + o), pv);
-        const unsigned char* ip = idx + o;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          if (ip[j] == tap && pv[j] > 0.f) acc[j] += d[j];
+      for (int b = 0; b < 2; ++b) {
+        const int q = a * 2 + b;
+        wok[q] = k + a < OH && m + b < OW;
+        const size_t o = (((size_t)n * OH + (wok[q] ? k + a : k)) * OW + (wok[q] ? m + b : m)) * C + c0;
+        unpack16<T>(ld16(dp + o), d[q]);
+        unpack16<T>(ld16(pooled + o), pv[q]);
+        if constexpr (VEC == 8) {
+          const uint2 t2 = *reinterpret_cast<const uint2*>(idx + o);
+          pk[q][0] = t2.x;
+          pk[q][1] = t2.y;
+        } else {
+          pk[q][0] = *reinterpret_cast<const unsigned*>(idx + o);
+          pk[q][1] = 0;
+        }
       }
+    // contribution of window q through tap `tap`, channel j
+    auto g = [&](int q, int tap, int j) -> float {
+      const int code = (int)((pk[q][j >> 2] >> (8 * (j & 3))) & 0xffu);
+      return (wok[q] && code == tap && pv[q][j] > 0.f) ? d[q][j] : 0.f;
+    };
+    float o00[VEC], o01[VEC], o10[VEC], o11[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      o00[j] = g(0, 4, j);
+      o01[j] = g(0, 5, j) + g(1, 3, j);
+      o10[j] = g(0, 7, j) + g(2, 1, j);
+      o11[j] = ((g(0, 8, j) + g(1, 6, j)) + g(2, 2, j)) + g(3, 0, j);
     }
-    st16(dz + pix * C + c0, pack16<T>(acc));
+    const int h0 = 2 * k, w0 = 2 * m;
+    T* base = dz + (((size_t)n * H + h0) * W + w0) * C + c0;
+    st16(base, pack16<T>(o00));
+    if (w0 + 1 < W) st16(base + C, pack16<T>(o01));
+    if (h0 + 1 < H) {
+      st16(base + (size_t)W * C, pack16<T>(o10));
+      if (w0 + 1 < W) st16(base + (size_t)W * C + C, pack16<T>(o11));
+    }
   }
 }
 
@@ -727,7 +759,7 @@ int ecg_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const un
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "maxpool bwd: C=%d unsupported", C);
   int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
-  int grid = ew_grid((long)N * H * W * (C / vec), EW_THREADS);
+  int grid = ew_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec), EW_THREADS);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(maxpool_relu_bwd_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, stream,
                                 (const bf16_t*)dp, (const bf16_t*)pooled, idx, (bf16_t*)dz, N, H, W, C, OH, OW),
