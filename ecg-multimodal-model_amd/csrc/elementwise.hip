@@ -360,29 +360,66 @@ __global__ __launch_bounds__(EW_THREADS) void bnrelu_maxpool_kernel(const T* __r
     int c0 = chunk * VEC;
     float best[VEC];
     int bi[VEC];
+    if constexpr (sizeof(T) == 2) {
+      // bf16: post-ReLU values are >= 0, so their bf16 bit patterns order like the values.  One sortable key per
+      // channel, (bits << 4) | (15 - tap): a single unsigned max implements "largest value, earliest tap on ties".
+      unsigned key[VEC];
+      float scv[VEC], shv[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      best[j] = -INFINITY;
-      bi[j] = 0;
-    }
+      for (int j = 0; j < VEC; ++j) {
+        key[j] = 0u;
+        scv[j] = coef[c0 + j];
+        shv[j] = coef[C + c0 + j];
+      }
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      int h = oh * 2 - 1 + kh;
-      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        int h = oh * 2 - 1 + kh;
+        if ((unsigned)h >= (unsigned)H) continue;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        int w = ow * 2 - 1 + kw;
-        if ((unsigned)w >= (unsigned)W) continue;
-        float f[VEC];
-        unpack16<T>(ld16(y + (((size_t)n * H + h) * W + w) * C + c0), f);
+        for (int kw = 0; kw < 3; ++kw) {
+          int w = ow * 2 - 1 + kw;
+          if ((unsigned)w >= (unsigned)W) continue;
+          float f[VEC];
+          unpack16<T>(ld16(y + (((size_t)n * H + h) * W + w) * C + c0), f);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float a = fmaxf(f[j] * coef[c0 + j] + coef[C + c0 + j], 0.f);
-          // value as it would be stored (so ties are decided on the stored precision)
-          if (sizeof(T) == 2) a = bf2f(f2bf(a));
-          if (a > best[j]) {
-            best[j] = a;
-            bi[j] = kh * 3 + kw;
+          for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j] * scv[j] + shv[j], 0.f);
+          const u32x4 r = pack16<bf16_t>(f);  // rounded as stored; (-0 cannot win: sign bit masked off)
+          const unsigned tcode = 15u - (unsigned)(kh * 3 + kw);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            key[2 * q] = max(key[2 * q], ((r[q] & 0x7fffu) << 4) | tcode);
+            key[2 * q + 1] = max(key[2 * q + 1], (((r[q] >> 16) & 0x7fffu) << 4) | tcode);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        best[j] = __uint_as_float((key[j] >> 4) << 16);
+        bi[j] = 15 - (int)(key[j] & 15u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        best[j] = -INFINITY;
+        bi[j] = 0;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        int h = oh * 2 - 1 + kh;
+        if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          int w = ow * 2 - 1 + kw;
+          if ((unsigned)w >= (unsigned)W) continue;
+          float f[VEC];
+          unpack16<T>(ld16(y + (((size_t)n * H + h) * W + w) * C + c0), f);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float a = fmaxf(f[j] * coef[c0 + j] + coef[C + c0 + j], 0.f);
+            if (a > best[j]) {
+              best[j] = a;
+              bi[j] = kh * 3 + kw;
+            }
           }
         }
       }
