@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--serialize", action="store_true", help="profiling aid: every kernel on ONE stream (no encoder / "
+                    "weight-gradient stream overlap), so rocprofv3 durations are per-kernel-alone; not the headline number")
     return ap.parse_args()
 
 
@@ -179,9 +181,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib = L.lib()
+    if args.serialize:
+        lib.ecgmm_side_wgrad(0)
+        if getattr(model, "config", None) is not None:
+            model.config.overlap_encoders = False
     for _ in range(args.warmup):
         step()
-    lib = L.lib()
     prof = not args.no_prof
     fence()
     if prof:
@@ -266,6 +272,8 @@ def main():
             "roofline": roof,
             "roofline_serialized": roof_serial,
         }
+        if args.serialize:
+            out["config"]["serialized_streams"] = True   # profiling configuration, not the headline number
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)

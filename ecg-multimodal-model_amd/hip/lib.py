@@ -13,7 +13,8 @@ RESNET18_NPARAMS, RESNET18_NBUFFERS = 62, 60
 RESNET1D_NPARAMS, RESNET1D_NBUFFERS = 52, 27
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libecgmm_hip.so")
+# ECGMM_LIB: A/B another build of the same library (kernel experiments); default = the in-tree build
+LIB_PATH = os.environ.get("ECGMM_LIB") or os.path.join(_PKG_DIR, "libecgmm_hip.so")
 
 vp, i32, i64, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
