@@ -12,7 +12,10 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="fwd,dgrad,wgrad")
 ap.add_argument("--layers", default="")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--lib", default="", help="A/B: path of another build of libecgmm_hip.so")
 a = ap.parse_args()
+if a.lib:
+    L.LIB_PATH = a.lib
 B, dt = a.batch, (L.BF16 if a.dtype == "bf16" else L.F32)
 tdt = torch.bfloat16 if dt == L.BF16 else torch.float32
 SHAPES = [  # name, H, W, Cin, Cout, R, S, stride, ph, pw
