@@ -3,7 +3,7 @@
 // 3x3/s2 max-pool (fused with BN+ReLU) and its backward, global average pool, layout packs.
 // All tensor traffic is 16 B per lane; each thread keeps a FIXED channel chunk (so per-channel
 // coefficients live in registers) and walks rows.
-#include "common.h"
+#include "ops.h"
 
 namespace {
 
@@ -589,6 +589,36 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// All conv weights of an encoder in ONE launch (a launch costs ~5 us of dependency latency, the copy itself ~1 us):
+// the descriptor table travels by value in the kernel arguments; a block finds its tensor by its block offset.
+struct PackBatch {
+  const float* w[ECG_PACK_MAX];
+  void* fwd[ECG_PACK_MAX];
+  void* dgr[ECG_PACK_MAX];
+  int cout[ECG_PACK_MAX], cin[ECG_PACK_MAX], rs[ECG_PACK_MAX];
+  int blk0[ECG_PACK_MAX + 1];  // first block of each tensor
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(PackBatch b) {
+  int t = 0;
+  while (t + 1 < b.n && (int)blockIdx.x >= b.blk0[t + 1]) ++t;
+  const int Cout = b.cout[t], Cin = b.cin[t], RS = b.rs[t];
+  const float* __restrict__ w = b.w[t];
+  T* __restrict__ fwd = (T*)b.fwd[t];
+  T* __restrict__ dgr = (T*)b.dgr[t];
+  const long total = (long)Cout * Cin * RS;
+  const int nb = b.blk0[t + 1] - b.blk0[t];
+  for (long i = (long)(blockIdx.x - b.blk0[t]) * 256 + threadIdx.x; i < total; i += (long)nb * 256) {
+    int tap = (int)(i % RS);
+    long r = i / RS;
+    int ci = (int)(r % Cin), co = (int)(r / Cin);
+    float v = w[i];
+    if (fwd) Elem<T>::st(fwd + ((size_t)co * RS + tap) * Cin + ci, v);
+    if (dgr) Elem<T>::st(dgr + ((size_t)ci * RS + tap) * Cout + co, v);
+  }
+}
+
 // NCHW f32 <-> NHWC T through a 32x32 LDS transpose (coalesced both ways)
 template <typename T, bool TO_NHWC>
 __global__ __launch_bounds__(256) void nchw_nhwc_kernel(const void* __restrict__ src_, void* __restrict__ dst_, int C,
@@ -856,6 +886,27 @@ int ecg_pack_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int 
                                 (float*)dgrad, Cout, Cin, RS),
              "pack_weight");
   ECG_CHECK_LAUNCH("pack_weight");
+  return 0;
+}
+
+int ecg_pack_weight_batch(int dtype, const EcgPackItem* items, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += ECG_PACK_MAX) {
+    PackBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = n - base < ECG_PACK_MAX ? n - base : ECG_PACK_MAX;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const EcgPackItem& it = items[base + i];
+      b.w[i] = it.w; b.fwd[i] = it.fwd; b.dgr[i] = it.dgrad; b.cout[i] = it.Cout; b.cin[i] = it.Cin; b.rs[i] = it.RS;
+      b.blk0[i] = blocks;
+      long nb = ((long)it.Cout * it.Cin * it.RS + 2047) / 2048;  // 8 elements per thread
+      blocks += (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    }
+    b.blk0[b.n] = blocks;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, b),
+               hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(blocks), dim3(256), 0, stream, b), "pack_weight_batch");
+    ECG_CHECK_LAUNCH("pack_weight_batch");
+  }
   return 0;
 }
 

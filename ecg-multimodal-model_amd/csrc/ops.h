@@ -41,6 +41,14 @@ int ecg_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const
 int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, hipStream_t stream);
 int ecg_se_gate_grad(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, float* dg,
                      int N, int R, int C, hipStream_t stream);
+constexpr int ECG_PACK_MAX = 24;
+struct EcgPackItem {
+  const float* w;  // OIHW / OIL fp32 master weight
+  void* fwd;       // [Cout][RS][Cin] compute dtype (nullable)
+  void* dgrad;     // [Cin][RS][Cout] compute dtype (nullable)
+  int Cout, Cin, RS;
+};
+int ecg_pack_weight_batch(int dtype, const EcgPackItem* items, int n, hipStream_t stream);
 int ecg_pack_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int Cout, int Cin, int RS,
                     hipStream_t stream);
 int ecg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, hipStream_t stream);

@@ -280,6 +280,19 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   const int dt = r.d.dtype, N = r.d.N;
   const int stats_rows = r.d.training ? 1 : 0;
 
+  // ---- every conv weight -> compute-dtype operand layouts, one launch
+  {
+    EcgPackItem items[ECG_PACK_MAX];
+    int n = 0;
+    for (int i = 0; i < 8; ++i) {
+      const BlockCfg& k = r.blk[i];
+      FwdWs::B& b = w.b[i];
+      items[n++] = {P(params, k.p_conv1), b.w1f, b.w1d, k.cout, k.cin, 9};
+      items[n++] = {P(params, k.p_conv2), b.w2f, b.w2d, k.cout, k.cout, 9};
+      if (k.down) items[n++] = {P(params, k.p_dconv), b.wdf, b.wdd, k.cout, k.cin, 1};
+    }
+    ECG_TRY(ecg_pack_weight_batch(dt, items, n, s));
+  }
   // ---- stem
   ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, 3, 7, s));
   ECG_TRY(ecg_stem_fwd(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
@@ -295,8 +308,6 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
     const int rows = ecg_conv_stats_rows(M);
     ConvGeom g1 = make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1);
     ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
-    ECG_TRY(ecg_pack_weight(dt, P(params, k.p_conv1), b.w1f, b.w1d, k.cout, k.cin, 9, s));
-    ECG_TRY(ecg_pack_weight(dt, P(params, k.p_conv2), b.w2f, b.w2d, k.cout, k.cout, 9, s));
     ECG_TRY(ecg_conv_igemm(dt, 0, g1, cur, b.w1f, b.y1, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
     ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_bn1, buffers, k.b_bn1, b.coef1, s));
     ECG_TRY(ecg_bn_act(dt, b.y1, b.coef1, nullptr, nullptr, nullptr, 1, 1, b.a1, M, k.cout, s));
@@ -304,7 +315,6 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
     ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, s));
     if (k.down) {
       ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
-      ECG_TRY(ecg_pack_weight(dt, P(params, k.p_dconv), b.wdf, b.wdd, k.cout, k.cin, 1, s));
       ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
       ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_dbn, buffers, k.b_dbn, b.coefd, s));
       ECG_TRY(ecg_bn_act(dt, b.y2, b.coef2, b.yd, b.coefd, nullptr, 1, 1, b.out, M, k.cout, s));

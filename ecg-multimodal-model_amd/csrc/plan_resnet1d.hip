@@ -218,6 +218,18 @@ extern "C" int ecgmm_resnet1d_forward(const ecgmm_resnet1d_desc* d, const float*
   const int dt = r.d.dtype, N = r.d.N, cin = r.d.cin;
   float* st = r.d.training ? w.stats : nullptr;
 
+  {  // every conv weight -> compute-dtype operand layouts, one launch
+    EcgPackItem items[ECG_PACK_MAX];
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+      const Blk1& k = r.blk[i];
+      Fwd1::B& b = w.b[i];
+      items[n++] = {P(params, k.p0 + 0), b.w1f, b.w1d, k.cout, k.cin, 3};
+      items[n++] = {P(params, k.p0 + 4), b.w2f, b.w2d, k.cout, k.cout, 3};
+      if (k.down) items[n++] = {P(params, k.p0 + 12), b.wdf, b.wdd, k.cout, k.cin, 1};
+    }
+    ECG_TRY(ecg_pack_weight_batch(dt, items, n, s));
+  }
   ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, cin, 1, s));
   ECG_TRY(ecg_stem_fwd(dt, signal, w.wstem, P(params, 1), w.y0, st, N, cin, 1, r.d.L, 1, s));
   ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, cin, 1, r.d.L, 1), 64, (long)N * r.L1, params, 2, buffers, 0,
@@ -233,8 +245,6 @@ extern "C" int ecgmm_resnet1d_forward(const ecgmm_resnet1d_desc* d, const float*
     const int rows = ecg_conv_stats_rows(M);
     ConvGeom g1 = make_geom(N, 1, k.lin, k.cin, k.cout, 1, 3, k.stride, 0, 1);
     ConvGeom g2 = make_geom(N, 1, k.lout, k.cout, k.cout, 1, 3, 1, 0, 1);
-    ECG_TRY(ecg_pack_weight(dt, P(params, p + 0), b.w1f, b.w1d, k.cout, k.cin, 3, s));
-    ECG_TRY(ecg_pack_weight(dt, P(params, p + 4), b.w2f, b.w2d, k.cout, k.cout, 3, s));
     ECG_TRY(ecg_conv_igemm(dt, 0, g1, cur, b.w1f, b.y1, P(params, p + 1), nullptr, st, 0, s));
     ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, p + 2, buffers, bb, b.coef1, s));
     ECG_TRY(ecg_bn_act(dt, b.y1, b.coef1, nullptr, nullptr, nullptr, 1, 1, b.a1, M, k.cout, s));
@@ -247,7 +257,6 @@ extern "C" int ecgmm_resnet1d_forward(const ecgmm_resnet1d_desc* d, const float*
                            s));
     if (k.down) {
       ConvGeom gd = make_geom(N, 1, k.lin, k.cin, k.cout, 1, 1, k.stride, 0, 0);
-      ECG_TRY(ecg_pack_weight(dt, P(params, p + 12), b.wdf, b.wdd, k.cout, k.cin, 1, s));
       ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, P(params, p + 13), nullptr, st, 0, s));
       ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, p + 14, buffers, bb + 6, b.coefd, s));
       ECG_TRY(ecg_bn_act(dt, b.y2, b.coef2, b.yd, b.coefd, b.g, k.lout, 1, b.out, M, k.cout, s));
