@@ -25,6 +25,12 @@ CONV_CASES = [
     (5, 1, 313, 128, 256, 1, 3, 2, 0, 1),    # Conv1d k3 s2 (H = 1), ragged L
     (4, 1, 157, 64, 128, 1, 1, 2, 0, 0),     # Conv1d k1 s2
     (7, 1, 1, 96, 40, 1, 1, 1, 0, 0),        # Linear-shaped, Cout not a tile multiple, Cin partial stage
+    # the weights-resident halo kernel (bf16, Cin/Cout <= 64, stride 1): tiles spanning images, 1-D, partial channels,
+    # and more tiles than workgroups (persistent loop, double-buffered halo)
+    (3, 9, 11, 64, 64, 3, 3, 1, 1, 1),
+    (6, 1, 300, 64, 64, 1, 3, 1, 0, 1),
+    (2, 20, 17, 32, 48, 3, 3, 1, 1, 1),
+    (16, 48, 48, 64, 64, 3, 3, 1, 1, 1),
 ]
 
 

@@ -12,6 +12,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="fwd,dgrad,wgrad")
 ap.add_argument("--layers", default="")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--no-stats", action="store_true", help="forward without the fused BatchNorm partial sums")
 ap.add_argument("--lib", default="", help="A/B: path of another build of libecgmm_hip.so")
 a = ap.parse_args()
 if a.lib:
@@ -46,7 +47,7 @@ for name, H, W, Cin, Cout, R, S, st, ph, pw in SHAPES:
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     flops = 2.0 * B * OH * OW * Cout * R * S * Cin
     runs = {
-        "fwd": lambda: lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(stats), 0, stream()),
+        "fwd": lambda: lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), None if a.no_stats else ptr(stats), 0, stream()),
         "dgrad": lambda: lib.ecgmm_conv_bwd_data(dt, C.byref(d), ptr(dy), ptr(w), None, ptr(dx), stream()),
         "wgrad": lambda: lib.ecgmm_conv_bwd_weight(dt, C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), nb, stream()),
     }
