@@ -1,0 +1,15 @@
+# Evidence for profiles/: the bench line, and rocprofv3 --kernel-trace --stats of the same command (headline = concurrent
+# streams; plus the one-stream --serialize variant, where a kernel's duration is its own).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final
+mkdir -p $O
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1 || exit 1
+python3 $R/tools/kstats.py $O/kt 13 60 > $O/kernel_stats.txt
+rocprofv3 --kernel-trace --stats -d $O/kts -o kt --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof --serialize > $O/kts.log 2>&1 || exit 1
+python3 $R/tools/kstats.py $O/kts 13 60 > $O/kernel_stats_serialized.txt
+python3 $R/bench.py --workload image_only --batch 128 --no-cpu-baseline > $O/bench_cfg2.json 2>/dev/null || exit 1
+python3 $R/bench.py --workload signal12 --batch 512 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null || exit 1
+python3 $R/bench.py --image-hw 250x2500 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f2.json 2>/dev/null || exit 1
+echo final-done
