@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const unsigned x_lane = cx < p.Cin ? (unsigned)cx * (unsigned)sizeof(T) : OOB;
   const unsigned dy_row_bytes = (unsigned)p.Cout * (unsigned)sizeof(T), x_pix_bytes = (unsigned)p.Cin * (unsigned)sizeof(T);
 
+  // filter width is 3 or 1 (taps = R*S in {1, 3, 9}); per-tap source deltas in bytes, wave-uniform
+  const bool s3 = p.S == 3;
+  unsigned tap_delta[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tap_delta[t] = (unsigned)((s3 ? t / 3 : t) * p.W + (s3 ? t % 3 : 0)) * x_pix_bytes;
   auto dma = [&](int stage, int step) {
     unsigned char* base = smem + stage * STAGE_BYTES + wv * 1024;
     const int pix = step * C::KP + drow;
@@ -110,13 +115,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const int ow = (int)rem - oh * p.OW;
     wg_dma16(rs_dy, base, (pok && dy_lane != OOB) ? (unsigned)(pix - (int)pix0) * dy_row_bytes + dy_lane : OOB);
     const int hb = oh * p.stride - p.pad_h, wb = ow * p.stride - p.pad_w;
-    const int nrow = (n - n0) * p.H;
+    // byte offset of tap (0,0)'s source pixel, once per step; tap (r, s) is a wave-uniform delta away.  (Per tap this
+    // used to be two quarter-rate 32-bit multiplies per lane plus a scalar division by S: with 9 taps per 36 MFMAs the
+    // kernel was VALU- and SALU-bound, 3.6 VALU + 2.7 SALU per MFMA.)
+    const unsigned off00 = (unsigned)(((n - n0) * p.H + hb) * p.W + wb) * x_pix_bytes + x_lane;
+    const bool lane_ok = pok && x_lane != OOB;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int r = t / p.S, s = t - r * p.S;
-      const int hs = hb + r, ws = wb + s;
-      const bool ok = pok && x_lane != OOB && (unsigned)hs < (unsigned)p.H && (unsigned)ws < (unsigned)p.W;
-      wg_dma16(rs_x, base + (1 + t) * TILE_BYTES, ok ? (unsigned)((nrow + hs) * p.W + ws) * x_pix_bytes + x_lane : OOB);
+      const int r = s3 ? t / 3 : t, s = s3 ? t % 3 : 0;  // (t is a constant after unrolling; s3 is wave-uniform)
+      const bool ok = lane_ok && (unsigned)(hb + r) < (unsigned)p.H && (unsigned)(wb + s) < (unsigned)p.W;
+      wg_dma16(rs_x, base + (1 + t) * TILE_BYTES, ok ? off00 + tap_delta[t] : OOB);
     }
   };
 
@@ -264,6 +272,7 @@ template <typename T>
 int launch_wgrad(const ConvGeom& g, WgradParams& p, int nsplit, hipStream_t stream) {
   const int RS = g.R * g.S;
   dim3 grid(ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64), nsplit);
+  if (g.S != 1 && g.S != 3) ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: filter width %d unsupported (1 or 3)", g.S);
   if (RS == 1) return launch_wgrad_nt<T, 1>(p, grid, stream);
   if (RS == 3) return launch_wgrad_nt<T, 3>(p, grid, stream);
   if (RS == 9) return launch_wgrad_nt<T, 9>(p, grid, stream);

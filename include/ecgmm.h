@@ -236,7 +236,7 @@ int ecgmm_image_transform(const void* img, float* out, int B, int H, int W, int 
 /* Measurement only (no reference counterpart): HIP-event timing of the conv kernels on their launch
  * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad.  collect()
  * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / algorithmic
- * HBM bytes / launches. */
+ * HBM bytes / launches.  enable(1) times every kind, enable(2) only kinds 0 and 1, enable(0) switches it off. */
 int ecgmm_prof_enable(int on);
 int ecgmm_prof_collect(int nkinds, double* ms, double* flops, double* bytes, int64_t* count);
 
