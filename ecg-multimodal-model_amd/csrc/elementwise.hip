@@ -201,11 +201,15 @@ struct BnBwdParams {
   int C, rows_per_sample;
 };
 
+// 1024-thread blocks: at most 256 partial rows per launch, which the finalize / bias-sum kernels fold themselves (a
+// separate fold launch per BatchNorm cost ~6 us of dependency latency, 29 times per step), at the same threads in flight.
+constexpr int BWD_THREADS = 1024;
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_kernel(BnBwdParams p) {
+__global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
   constexpr int VEC = Elem<T>::VEC;
-  __shared__ float shm[EW_THREADS][2 * VEC + 1];
-  const int cpr = p.C / VEC, rpi = EW_THREADS / cpr;
+  extern __shared__ float shm_dyn[];
+  float(*shm)[2 * VEC + 1] = reinterpret_cast<float(*)[2 * VEC + 1]>(shm_dyn);  // [BWD_THREADS][2*VEC+1]
+  const int cpr = p.C / VEC, rpi = BWD_THREADS / cpr;
   const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
   const int c0 = chunk * VEC;
   float mean[VEC], inv[VEC], k1[VEC], k2[VEC], k3[VEC], a1[VEC], a2[VEC], msc[VEC], msh[VEC];
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_kernel(BnBwdParams p) {
       if (!APPLY) shm[threadIdx.x][VEC + j] = a2[j];
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < NQ * p.C; o += EW_THREADS) {
+    for (int o = threadIdx.x; o < NQ * p.C; o += BWD_THREADS) {
       int which = o / p.C, c = o % p.C;
       int ck = c / VEC, j = c % VEC;
       float s = 0.f;
@@ -700,7 +704,7 @@ int ecg_bn_rows(int dtype, long M, int C) {
 // Long partial-row buffers are first folded to ECG_TAIL_ROWS rows written into the buffer's tail
 // (callers size partial buffers for rows + ECG_TAIL_ROWS rows), so the finalize kernels stay short.
 static int fold_rows(const float*& partial, int& rows, int width, hipStream_t stream) {
-  if (rows <= 128) return 0;  // the finalize kernels fold short buffers themselves (16 slices x 8 iterations)
+  if (rows <= 256) return 0;  // the finalize kernels fold short buffers themselves (16 slices x 16 iterations)
   float* tail = const_cast<float*>(partial) + (size_t)rows * width;
   int chunk = ceil_div(rows, ECG_TAIL_ROWS);
   int nb = ceil_div(rows, chunk);
@@ -758,16 +762,33 @@ int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, con
   return 0;
 }
 
+static int bn_bwd_rows(int dtype, long M, int C) {
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  int rpi = BWD_THREADS / (C / vec);
+  int g = ew_grid(M, rpi * 8);
+  return g > 256 ? 256 : g;
+}
+template <typename T, bool APPLY>
+static void bn_bwd_launch(const BnBwdParams& p, int grid, hipStream_t stream) {
+  constexpr size_t lds = (size_t)BWD_THREADS * (2 * Elem<T>::VEC + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)bn_bwd_kernel<T, APPLY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bn_bwd_kernel<T, APPLY>), dim3(grid), dim3(BWD_THREADS), lds, stream, p);
+}
+
 // full BN backward: reduce -> finalize -> apply.  scratch: partial rows [rows][2][C] + bcoef [3][C]
 size_t ecg_bn_bwd_scratch(int dtype, long M, int C) {
-  return ((size_t)(ecg_bn_rows(dtype, M, C) + ECG_TAIL_ROWS) * 2 * C + 3 * C) * sizeof(float);
+  return ((size_t)(bn_bwd_rows(dtype, M, C) + ECG_TAIL_ROWS) * 2 * C + 3 * C) * sizeof(float);
 }
 
 int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
                int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma, float* dbeta,
                void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
-  int grid = ecg_bn_rows(dtype, M, C);
+  int grid = bn_bwd_rows(dtype, M, C);
   float* partial = scratch;
   float* bcoef = scratch + (size_t)(grid + ECG_TAIL_ROWS) * 2 * C;
   BnBwdParams p;
@@ -775,13 +796,11 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   p.dout = dout; p.maskref = maskref; p.gate = gate; p.addc = addc; p.y = y; p.coef = coef; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   p.partial = partial;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false>), dim3(grid), dim3(EW_THREADS), 0, stream, p),
-             hipLaunchKernelGGL((bn_bwd_kernel<float, false>), dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_bwd");
+  DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, false>(p, grid, stream)), (bn_bwd_launch<float, false>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_reduce");
   {
     const float* pr = partial;
-    int rows = grid;
-    ECG_TRY(fold_rows(pr, rows, 2 * C, stream));
+    int rows = grid;  // <= 256: folded by the finalize kernel itself (16 slices x 16 rows)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, pr, rows, C, (double)M,
                        gamma, coef, dgamma, dbeta, bcoef);
   }
@@ -789,8 +808,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   if (!dy) return 0;
   p.bcoef = bcoef; p.dy = dy; p.dz_out = dz_out;
   p.partial = dbias ? partial : nullptr;  // reuse (finalize already consumed it; stream-ordered)
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, true>), dim3(grid), dim3(EW_THREADS), 0, stream, p),
-             hipLaunchKernelGGL((bn_bwd_kernel<float, true>), dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_bwd");
+  DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");
   if (dbias) {
     hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, grid, C, dbias, 0);
