@@ -696,6 +696,7 @@ inline bool chunk_ok(int C, int dtype) {
 
 int ecg_bn_rows(int dtype, long M, int C) {
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  if (C < vec) return 1;  // (unsupported width: the kernel launchers reject it with a shape error)
   int rpi = EW_THREADS / (C / vec);
   int g = ew_grid(M, rpi * 8);
   return g > 1024 ? 1024 : g;
@@ -764,6 +765,7 @@ int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, con
 
 static int bn_bwd_rows(int dtype, long M, int C) {
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  if (C < vec) return 1;
   int rpi = BWD_THREADS / (C / vec);
   int g = ew_grid(M, rpi * 8);
   return g > 256 ? 256 : g;

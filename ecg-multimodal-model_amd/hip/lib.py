@@ -93,6 +93,17 @@ SIGNATURES = {
     "ecgmm_axpby": (i32, [f32, vp, f32, vp, i64, vp]),
     "ecgmm_signal_preprocess_workspace": (sz, [i32, i32, i32]),
     "ecgmm_signal_preprocess": (i32, [vp, vp, i32, i32, vp, vp, i32, P(f64), P(f64), P(f64), i32, vp, sz, vp]),
+    "ecgmm_glu_fwd": (i32, [vp, vp, i64, i32, vp]),
+    "ecgmm_glu_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "ecgmm_sparsemax_fwd": (i32, [vp, vp, i64, i32, vp]),
+    "ecgmm_sparsemax_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "ecgmm_ew": (i32, [i32, vp, vp, vp, i64, f32, vp]),
+    "ecgmm_split_cols": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
+    "ecgmm_split_cols_bwd": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "ecgmm_bn_small_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp]),
+    "ecgmm_bn_small_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ecgmm_entropy_fwd": (i32, [vp, vp, i64, i32, f32, vp]),
+    "ecgmm_entropy_bwd": (i32, [vp, vp, vp, i64, i32, f32, vp]),
     "ecgmm_image_resize_tables_bytes": (sz, [i32, i32, i32, i32]),
     "ecgmm_image_resize_tables": (i32, [i32, i32, i32, i32, vp, sz]),
     "ecgmm_image_transform": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, P(f32), P(f32), vp]),

@@ -117,9 +117,7 @@ class ECGMultimodalModel(nn.Module):
         cd = getattr(config, "compute_dtype", "bf16")
 
         self.modal_dim = getattr(config, "modal_dim", 256)
-        self.image_dim = self.modal_dim
-        self.signal_dim = self.modal_dim
-        self.clinical_dim = self.modal_dim
+        self.image_dim, self.signal_dim, self.clinical_dim = self._branch_dims()
 
         # image encoder (ResNet18) + LayerNorm
         self.image_encoder = resnet18(compute_dtype=cd)
@@ -132,13 +130,7 @@ class ECGMultimodalModel(nn.Module):
 
         # clinical encoder + LayerNorm
         p = getattr(config, "dropout", 0.3)
-        self.clinical_encoder = hnn.Sequential(
-            hnn.Linear(self.get_clinical_feature_dim(), 64),
-            hnn.BatchNorm1d(64),
-            nn.ReLU(),
-            nn.Dropout(p),
-            hnn.Linear(64, self.clinical_dim),
-        )
+        self.clinical_encoder = self._build_clinical_encoder(p)
         self.clinical_norm = hnn.LayerNorm(self.clinical_dim)
 
         # branch classifiers
@@ -164,6 +156,22 @@ class ECGMultimodalModel(nn.Module):
 
     def get_clinical_feature_dim(self):
         return getattr(self.config, "clinical_input_dim", 24)
+
+    # ---- the two hooks in which multimodal.py's variant of this model differs (ecgmm/multimodal.py)
+    def _branch_dims(self):
+        return self.modal_dim, self.modal_dim, self.modal_dim
+
+    def _build_clinical_encoder(self, p):
+        return hnn.Sequential(
+            hnn.Linear(self.get_clinical_feature_dim(), 64),
+            hnn.BatchNorm1d(64),
+            nn.ReLU(),
+            nn.Dropout(p),
+            hnn.Linear(64, self.clinical_dim),
+        )
+
+    def _clinical_forward(self, clinical):
+        return self.clinical_encoder(clinical)
 
     def load_pretrained_signal_encoder(self, weight_path, load_fc=False):
         checkpoint = torch.load(weight_path, map_location="cpu")
@@ -197,7 +205,7 @@ class ECGMultimodalModel(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 signal_raw = self.signal_encoder(ecg_signal)
-                clinical_raw = self.clinical_encoder(clinical)
+                clinical_raw = self._clinical_forward(clinical)
             image_raw = self.image_encoder(image)
             main.wait_stream(side)
             signal_raw.record_stream(main)
@@ -205,7 +213,7 @@ class ECGMultimodalModel(nn.Module):
         else:
             image_raw = self.image_encoder(image)
             signal_raw = self.signal_encoder(ecg_signal)
-            clinical_raw = self.clinical_encoder(clinical)
+            clinical_raw = self._clinical_forward(clinical)
         img_feat = self.image_norm(image_raw)
         signal_feat = self.signal_norm(signal_raw)
         clinical_feat = self.clinical_norm(clinical_raw)

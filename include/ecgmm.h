@@ -221,6 +221,30 @@ int ecgmm_signal_preprocess(const float* x, float* out, int S, int L, const floa
                             int window, const double* b, const double* a, const double* zi, int order, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* SURVEY 8(f3) -- the TabNet clinical encoder of multimodal.py:109-148 (pytorch_tabnet.tab_network.TabNetNoEmbeddings:
+ * third-party, source and version absent from the reference; restated from its published algorithm).  Row kernels,
+ * fp32: GLU gate out = z[:, :D] * sigmoid(z[:, D:]) of a [N, 2D] tensor; sparsemax along rows of [N, D], D <= 64;
+ * elementwise helpers of the mask / prior recurrence; mean_n sum_d M log(M + eps). */
+enum { ECGMM_EW_MUL = 0, ECGMM_EW_ADD_SCALE = 1, ECGMM_EW_PRIOR = 2, ECGMM_EW_RELU = 3, ECGMM_EW_RELU_BWD = 4,
+       ECGMM_EW_SCALE = 5, ECGMM_EW_NEG_MUL = 6, ECGMM_EW_ADD = 7, ECGMM_EW_RSUB = 8 };
+int ecgmm_glu_fwd(const float* z, float* out, int64_t N, int D, void* stream);
+int ecgmm_glu_bwd(const float* z, const float* dout, float* dz, int64_t N, int D, void* stream);
+int ecgmm_sparsemax_fwd(const float* x, float* p, int64_t N, int D, void* stream);
+int ecgmm_sparsemax_bwd(const float* p, const float* dp, float* dx, int64_t N, int D, void* stream);
+int ecgmm_ew(int op, const float* a, const float* b, float* out, int64_t n, float s, void* stream);
+/* x [N, D] -> d = x[:, :nd] (through ReLU when relu != 0), a = x[:, nd:]; bwd merges (gd / ga may be NULL = zero) */
+int ecgmm_split_cols(const float* x, float* d, float* a, int64_t N, int D, int nd, int relu, void* stream);
+int ecgmm_split_cols_bwd(const float* d, const float* gd, const float* ga, float* gx, int64_t N, int D, int nd, int relu,
+                         void* stream);
+/* BatchNorm1d over the rows of a small [N, C] fp32 matrix, any C (one block per channel): the 2- / 64- / 128-wide
+ * (ghost) batch norms of TabNet.  save = [2][C] mean, invstd.  accumulate != 0 adds into dgamma / dbeta. */
+int ecgmm_bn_small_fwd(const float* x, const float* gamma, const float* beta, float* rm, float* rv, long long* nbt,
+                       float* y, float* save, int N, int C, int training, float momentum, float eps, void* stream);
+int ecgmm_bn_small_bwd(const float* x, const float* dy, const float* gamma, const float* save, float* dx, float* dgamma,
+                       float* dbeta, int N, int C, int accumulate, void* stream);
+int ecgmm_entropy_fwd(const float* M, float* out, int64_t N, int D, float eps, void* stream);
+int ecgmm_entropy_bwd(const float* M, const float* g, float* dM, int64_t N, int D, float eps, void* stream);
+
 /* SURVEY 8(f1), image half: Resize((OH, OW)) -> ToTensor -> Normalize(mean, std) of decoded RGB pictures
  * (dataset.py:61,119-123; train_image_only.py:58-62; dataset_image.py:67-70 when OH==H && OW==W).
  * torchvision hands a PIL picture to Pillow's antialiased BILINEAR resample (8 bpc, two passes, 22-bit

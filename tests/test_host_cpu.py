@@ -94,6 +94,24 @@ def test_file_datasets_follow_the_reference_tables(tmp_path):
     assert np.allclose(sig.numpy(), ecg.loc[index].values.astype(np.float32))
 
 
+def test_tabnet_restatement_and_multimodal_py_variant_keys():
+    """f3 host side: sparsemax known answer, the pytorch_tabnet key layout, and that ecgmm.multimodal's model (TabNet
+    clinical branch, widths 512 / 128 / 32) has the state-dict of the restated multimodal.py model"""
+    from oracle import tabnet_ref as T
+    from ecgmm.multimodal import ECGMultimodalModel as TabNetVariant
+    p = T.sparsemax(torch.tensor([[0.5, 0.2, -1.0], [3.0, 1.0, 0.0]]))
+    assert torch.allclose(p, torch.tensor([[0.65, 0.35, 0.0], [1.0, 0.0, 0.0]]), atol=1e-6)
+    ref = T.multimodal_tabnet_model(2)
+    ours = TabNetVariant(Config)
+    assert list(ours.state_dict()) == list(ref.state_dict())
+    assert [tuple(v.shape) for v in ours.state_dict().values()] == [tuple(v.shape) for v in ref.state_dict().values()]
+    keys = [k for k in ours.state_dict() if k.startswith("clinical_encoder.")]
+    assert len(keys) == 120 and "clinical_encoder.tabnet.encoder.initial_splitter.shared.glu_layers.0.fc.weight" in keys
+    assert "clinical_encoder.tabnet.final_mapping.weight" in keys
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ours.clinical_encoder(torch.zeros(4, 2))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
