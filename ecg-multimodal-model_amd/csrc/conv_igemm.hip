@@ -212,10 +212,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
         int row = wp * 64 + b * 16 + fr;
         fb[b] = *reinterpret_cast<const u32x4*>(sX + row * ROWB + ((lch ^ (row & 7)) << 4));
       }
+      // (raised issue priority over the MFMA block: +5 % on the long-K layers 3-4, a loss on the 16-MFMA stages of BN = 64)
+      if (BN == 128) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < TC; ++a)
 #pragma unroll
         for (int b = 0; b < TP; ++b) Mma<T>::run(acc[a][b], fa[a], fb[b]);
+      if (BN == 128) __builtin_amdgcn_s_setprio(0);
     }
   };
 
