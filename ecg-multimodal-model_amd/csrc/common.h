@@ -106,6 +106,23 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// bf16 MFMA with the accumulator tied in place.  With the builtin, loops whose accumulator arrays live across several
+// basic blocks (the stem kernels' k-step loops) come out of register allocation with the tiles shifted between
+// iterations and a v_accvgpr_read / _write pair per accumulator register per iteration; an asm operand tied "+a"
+// cannot move.  hipcc does not pad hazards of asm statements: the leading s_nop 1 covers a VALU-written A/B operand,
+// no accumulator may be used by two consecutive MFMAs, and mfma_drain() must follow the last one before any other
+// instruction reads an accumulator.
+__device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const u32x4& a, const u32x4& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void mfma_drain() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // >= 18 wait states: last MFMA's D -> any reader
+#endif
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 static inline size_t dtype_size(int dt) { return dt == ECGMM_BF16 ? 2 : 4; }

@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
         u32x4 fa = *reinterpret_cast<const u32x4*>(sW + (a * 16 + fr) * WS + ks * 32 + fq * 8);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
-                                                              __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+          mfma_bf16_inplace(acc[a][b], fa, fb[b]);
       }
     } else {
       // f32: the k index of a 16x16x4 step is the lane quad; walk the 4 groups x 8 taps of this kstep
@@ -227,6 +226,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
   }
 
+  if (sizeof(T) == 2) mfma_drain();
   // epilogue: lane = pixel fr of tile b, channels a*16 + fq*4 + j
   T* y = (T*)p.y;
 #pragma unroll
@@ -382,8 +382,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
           u32x4 fb = pack16<bf16_t>(bv);
 #pragma unroll
           for (int a = 0; a < 4; ++a)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
-                                                                __builtin_bit_cast(bf16x8_t, fb), acc[a][b], 0, 0, 0);
+            mfma_bf16_inplace(acc[a][b], fa[a], fb);
         }
       }
     } else {
@@ -403,6 +402,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     }
   }
 
+  if (sizeof(T) == 2) mfma_drain();
   // D[row = co = a*16 + fq*4 + j][col = kidx]
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
