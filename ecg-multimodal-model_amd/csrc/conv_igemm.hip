@@ -236,6 +236,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   T* __restrict__ dst = (T*)p.dst;
   const T* __restrict__ addend = (const T*)p.addend;
   const bool vec_ok = (p.Cd & 3) == 0;
+  // bf16 with whole 32-channel groups in range: the 8-byte packs of two neighbouring channel tiles are exchanged
+  // between lane rows (v_permlane16_swap) so that every lane stores 16 B and an instruction writes 64 contiguous
+  // bytes per pixel.  (8 B per lane = 32-byte segments: WRITE_SIZE showed ~1.45x the output bytes.)
+  const bool wide = sizeof(T) == 2 && (p.Cd & 31) == 0;
+  uint2 opk[TC][TP];
+  int wpix[TP];
 #pragma unroll
   for (int a = 0; a < TC; ++a) {
     const int ch0 = n0 + wc * (BN / 2) + a * 16 + fq * 4;
@@ -283,6 +289,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
+      if (wide) {
+        opk[a][b].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        opk[a][b].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        wpix[b] = pok ? pix : -1;
+      }
       if (pok) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -290,7 +301,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
           s2[j] += v[j] * v[j];
         }
         T* o = dst + (size_t)pix * p.Cd + ch0;
-        if (vec_ok && ch0 + 3 < p.Cd) {
+        if (wide) {
+        } else if (vec_ok && ch0 + 3 < p.Cd) {
           if (sizeof(T) == 2) {
             uint2 pk;
             pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
@@ -323,6 +335,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
           }
       }
     }
+  }
+  if (wide) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int a = 0; a < TC; a += 2)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        // rows of 16 lanes = fq: after the swaps an even-fq lane holds [its own tile-a pack | its right neighbour's],
+        // an odd-fq lane [its left neighbour's tile-(a+1) pack | its own]: 8 consecutive channels either way
+        auto lo = __builtin_amdgcn_permlane16_swap(opk[a][b].x, opk[a + 1][b].x, false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(opk[a][b].y, opk[a + 1][b].y, false, false);
+        const int ch = n0 + wc * (BN / 2) + ((fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4);
+        if (wpix[b] >= 0 && n0 + wc * (BN / 2) + a * 16 < p.Cd)  // (Cd % 32 == 0: a pair is wholly in or out of range)
+          *reinterpret_cast<u32x4*>(dst + (size_t)wpix[b] * p.Cd + ch) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+      }
+#endif
   }
 }
 

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   if (sizeof(T) == 2) mfma_drain();
   // epilogue: lane = pixel fr of tile b, channels a*16 + fq*4 + j
   T* y = (T*)p.y;
+  // bf16: the 8-byte packs of neighbouring channel tiles are exchanged between lane rows (v_permlane16_swap) so every
+  // lane stores 16 B and an instruction writes 64 contiguous bytes per pixel (see conv_igemm.hip's epilogue)
+  uint2 opk[4][2];
+  bool ook[2] = {false, false};
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int ch0 = a * 16 + fq * 4;
@@ -251,10 +255,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
         }
         T* o = y + (((size_t)n * p.OH + oh) * p.OW + ow) * STEM_CO + ch0;
         if (sizeof(T) == 2) {
-          uint2 pk;
-          pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(o) = pk;
+          opk[a][b].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          opk[a][b].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          ook[b] = true;
         } else {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -276,6 +279,21 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
       }
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (sizeof(T) == 2) {
+#pragma unroll
+    for (int a = 0; a < 4; a += 2)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        auto lo = __builtin_amdgcn_permlane16_swap(opk[a][b].x, opk[a + 1][b].x, false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(opk[a][b].y, opk[a + 1][b].y, false, false);
+        const int ch = (fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4;
+        if (ook[b])
+          *reinterpret_cast<u32x4*>(y + (((size_t)n * p.OH + oh0 + prow[b]) * p.OW + ow0 + pcol[b]) * STEM_CO + ch) =
+              (u32x4){lo[0], hi[0], lo[1], hi[1]};
+      }
+  }
+#endif
   }  // tile loop
 }
 
