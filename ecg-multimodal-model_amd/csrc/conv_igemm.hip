@@ -56,6 +56,18 @@ struct IgemmParams {
   int act;
 };
 
+#ifdef ECG_STAMP
+// Diagnostic build only (make stamp): s_memtime brackets around the three segments of a K-loop iteration, summed per
+// launch by wave 0 of every workgroup.  Shares, not lengths, are what this build is good for (cdna guide, in-kernel stamps).
+__device__ unsigned long long g_stamp[8];
+#define ECG_STAMP_AT(t)                                                                   \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#endif
+
 constexpr int BM = 128;       // pixels per workgroup
 constexpr int ROWB = 128;     // bytes of K per LDS row per stage
 constexpr int NTHREADS = 256;
@@ -226,11 +238,31 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     dma(0);
     __syncthreads();  // (drains vmcnt: the LDS-DMA of stage 0 has landed for every wave)
   }
+#ifdef ECG_STAMP
+  unsigned long long sA = 0, sB = 0, sC = 0, t0, t1, t2, t3, tk0, tk1;
+  ECG_STAMP_AT(tk0);
+#endif
   for (int it = 0; it < nk; ++it) {
+#ifdef ECG_STAMP
+    ECG_STAMP_AT(t0);
+#endif
     if (it + 1 < nk) dma((it + 1) & 1);  // that buffer was last read in iteration it-1, fenced by its barrier
+#ifdef ECG_STAMP
+    ECG_STAMP_AT(t1);
+#endif
     compute(it & 1);
+#ifdef ECG_STAMP
+    ECG_STAMP_AT(t2);
+#endif
     __syncthreads();
+#ifdef ECG_STAMP
+    ECG_STAMP_AT(t3);
+    sA += t1 - t0; sB += t2 - t1; sC += t3 - t2;
+#endif
   }
+#ifdef ECG_STAMP
+  ECG_STAMP_AT(tk1);
+#endif
 
   // ---- epilogue: lane owns pixel (fr) x 4 consecutive channels (fq*4 + j) of each 16x16 tile
   T* __restrict__ dst = (T*)p.dst;
@@ -240,6 +272,91 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   // between lane rows (v_permlane16_swap) so that every lane stores 16 B and an instruction writes 64 contiguous
   // bytes per pixel.  (8 B per lane = 32-byte segments: WRITE_SIZE showed ~1.45x the output bytes.)
   const bool wide = sizeof(T) == 2 && (p.Cd & 31) == 0;
+#ifdef ECG_STAMP
+  unsigned long long te1;
+#endif
+  // Fast path for the common case -- whole tile in range, bf16, not a parity class (bias / addend / ReLU by uniform branches):
+  // straight-line code with no per-lane branches (the generic epilogue below is ~3000 instructions with ~250
+  // exec-mask branches; in-kernel stamps showed it holding 12-30 % of a workgroup's lifetime).
+  bool fast = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(T) == 2 && !PAR) {
+    fast = wide && m0 + BM <= Mc && n0 + BN <= p.Cd;
+    if (fast) {
+      T* row0 = dst + (size_t)(m0 + wp * 64 + fr) * p.Cd + n0 + wc * (BN / 2);
+      const size_t bstride = (size_t)16 * p.Cd;
+      float s1[TC][4], s2[TC][4];
+      f32x4 bias4[TC];
+#pragma unroll
+      for (int a = 0; a < TC; ++a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[a][j] = s2[a][j] = 0.f;
+        bias4[a] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * (BN / 2) + a * 16 + fq * 4)
+                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int a = 0; a < TC; a += 2)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+          f32x4 v0 = acc[a][b], v1 = acc[a + 1][b];
+          if (p.bias) {
+            v0 += bias4[a];
+            v1 += bias4[a + 1];
+          }
+          if (addend) {  // the lane's own 2 x 4 channels of this pixel: two 8-byte loads
+            const T* ap = addend + (size_t)(row0 - dst) + b * bstride + fq * 4;
+            const uint2 p0 = *reinterpret_cast<const uint2*>(ap + a * 16), p1 = *reinterpret_cast<const uint2*>(ap + (a + 1) * 16);
+            v0 += (f32x4){__uint_as_float(p0.x << 16), __uint_as_float(p0.x & 0xFFFF0000u), __uint_as_float(p0.y << 16),
+                          __uint_as_float(p0.y & 0xFFFF0000u)};
+            v1 += (f32x4){__uint_as_float(p1.x << 16), __uint_as_float(p1.x & 0xFFFF0000u), __uint_as_float(p1.y << 16),
+                          __uint_as_float(p1.y & 0xFFFF0000u)};
+          }
+          if (p.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v0[j] = fmaxf(v0[j], 0.f);
+              v1[j] = fmaxf(v1[j], 0.f);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s1[a][j] += v0[j];
+            s2[a][j] += v0[j] * v0[j];
+            s1[a + 1][j] += v1[j];
+            s2[a + 1][j] += v1[j] * v1[j];
+          }
+          const unsigned x0 = (unsigned)f2bf(v0[0]) | ((unsigned)f2bf(v0[1]) << 16);
+          const unsigned y0 = (unsigned)f2bf(v0[2]) | ((unsigned)f2bf(v0[3]) << 16);
+          const unsigned x1 = (unsigned)f2bf(v1[0]) | ((unsigned)f2bf(v1[1]) << 16);
+          const unsigned y1 = (unsigned)f2bf(v1[2]) | ((unsigned)f2bf(v1[3]) << 16);
+          auto lo = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+          auto hi = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
+          const int ch = (fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4;
+          *reinterpret_cast<u32x4*>(row0 + b * bstride + ch) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+        }
+      if (p.stats) {
+        float* srow = p.stats + (size_t)(mt * 2 + wp) * 2 * p.Cd + n0 + wc * (BN / 2) + fq * 4;
+#pragma unroll
+        for (int a = 0; a < TC; ++a) {
+          f32x4 r1, r2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r1[j] = row16_sum(s1[a][j]);
+            r2[j] = row16_sum(s2[a][j]);
+          }
+          if (fr == 0) {
+            *reinterpret_cast<f32x4*>(srow + a * 16) = r1;
+            *reinterpret_cast<f32x4*>(srow + p.Cd + a * 16) = r2;
+          }
+        }
+      }
+#ifdef ECG_STAMP
+      ECG_STAMP_AT(te1);
+#endif
+    }
+  }
+#endif
+  if (!fast) {
   uint2 opk[TC][TP];
   int wpix[TP];
 #pragma unroll
@@ -336,6 +453,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       }
     }
   }
+#ifdef ECG_STAMP
+  ECG_STAMP_AT(te1);
+#endif
   if (wide) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -352,7 +472,34 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       }
 #endif
   }
+  }  // generic epilogue
+#ifdef ECG_STAMP
+  {
+    unsigned long long te;
+    ECG_STAMP_AT(te);
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_stamp[0], sA);
+      atomicAdd(&g_stamp[1], sB);
+      atomicAdd(&g_stamp[2], sC);
+      atomicAdd(&g_stamp[3], te1 - tk1);    // epilogue part 1: values, BatchNorm sums, packing
+      atomicAdd(&g_stamp[4], tk1 - tk0);    // K loop
+      atomicAdd(&g_stamp[5], te - tk1);     // epilogue
+      atomicAdd(&g_stamp[6], 1ull);         // workgroups
+    }
+  }
+#endif
 }
+
+#ifdef ECG_STAMP
+extern "C" int ecgmm_stamp_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 template <typename T, int BN, int MODE, int ST>
 int launch_one(const IgemmParams& p, hipStream_t stream) {
