@@ -280,11 +280,21 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   // exec-mask branches; in-kernel stamps showed it holding 12-30 % of a workgroup's lifetime).
   bool fast = false;
 #if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (sizeof(T) == 2 && !PAR) {
+  if constexpr (sizeof(T) == 2) {
     fast = wide && m0 + BM <= Mc && n0 + BN <= p.Cd;
     if (fast) {
-      T* row0 = dst + (size_t)(m0 + wp * 64 + fr) * p.Cd + n0 + wc * (BN / 2);
-      const size_t bstride = (size_t)16 * p.Cd;
+      // element offset of this lane's pixel of fragment b (a parity class enumerates its own sub-lattice)
+      size_t prow[TP];
+#pragma unroll
+      for (int b = 0; b < TP; ++b) {
+        int pix = m0 + wp * 64 + b * 16 + fr;
+        if (PAR) {
+          const int n = pix / HWd, rem = pix - n * HWd;
+          const int h2 = rem / Wc, w2 = rem - h2 * Wc;
+          pix = (n * p.Hd + h2 * 2 + ph) * p.Wd + w2 * 2 + pw;
+        }
+        prow[b] = (size_t)pix * p.Cd + n0 + wc * (BN / 2);
+      }
       float s1[TC][4], s2[TC][4];
       f32x4 bias4[TC];
 #pragma unroll
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
             v1 += bias4[a + 1];
           }
           if (addend) {  // the lane's own 2 x 4 channels of this pixel: two 8-byte loads
-            const T* ap = addend + (size_t)(row0 - dst) + b * bstride + fq * 4;
+            const T* ap = addend + prow[b] + fq * 4;
             const uint2 p0 = *reinterpret_cast<const uint2*>(ap + a * 16), p1 = *reinterpret_cast<const uint2*>(ap + (a + 1) * 16);
             v0 += (f32x4){__uint_as_float(p0.x << 16), __uint_as_float(p0.x & 0xFFFF0000u), __uint_as_float(p0.y << 16),
                           __uint_as_float(p0.y & 0xFFFF0000u)};
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
           auto lo = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
           auto hi = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
           const int ch = (fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4;
-          *reinterpret_cast<u32x4*>(row0 + b * bstride + ch) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+          *reinterpret_cast<u32x4*>(dst + prow[b] + ch) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
         }
       if (p.stats) {
         float* srow = p.stats + (size_t)(mt * 2 + wp) * 2 * p.Cd + n0 + wc * (BN / 2) + fq * 4;

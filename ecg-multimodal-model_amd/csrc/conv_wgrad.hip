@@ -201,6 +201,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   // ---- slab store: D[row = co][col = ci]; lane: ci = fr, co = fq*4 + j
   const int RS = NT;
+  if (co0 + 64 <= p.Cout && ci0 + 64 <= p.Cin) {  // whole tile in range: no per-element branches
+    float* base = p.slab + (((size_t)split * RS) * p.Cout + co0 + wco * 32 + fq * 4) * p.Cin + ci0 + wci * 32 + fr;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            base[((size_t)t * p.Cout + a * 16 + j) * p.Cin + b * 16] = acc[t][a][b][j];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
