@@ -304,6 +304,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
         bias4[a] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wc * (BN / 2) + a * 16 + fq * 4)
                           : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
+#ifdef ECG_STAMP
+      unsigned long long tf0;
+      ECG_STAMP_AT(tf0);
+#endif
 #pragma unroll
       for (int a = 0; a < TC; a += 2)
 #pragma unroll
@@ -344,6 +348,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
           const int ch = (fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4;
           *reinterpret_cast<u32x4*>(dst + prow[b] + ch) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
         }
+#ifdef ECG_STAMP
+      unsigned long long tf1;
+      ECG_STAMP_AT(tf1);
+      if (threadIdx.x == 0) {
+        atomicAdd(&g_stamp[7], tf1 - tf0);   // pair loop: values, packing, swaps, stores
+      }
+#endif
       if (p.stats) {
         float* srow = p.stats + (size_t)(mt * 2 + wp) * 2 * p.Cd + n0 + wc * (BN / 2) + fq * 4;
 #pragma unroll

@@ -32,6 +32,25 @@ __device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rs, unsigned cha
 #endif
 }
 
+#ifdef ECG_STAMP
+// diagnostic build only (make stamp; tools/stamp_igemm.py --wgrad): see conv_igemm.hip
+__device__ unsigned long long g_wstamp[8];
+#define ECG_WSTAMP_AT(t)                                                                 \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+extern "C" int ecgmm_wstamp_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wstamp), sizeof(g_wstamp)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wstamp), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
 // Every tile is KP pixel rows x 64 channels = 4 KiB, filled by ONE 1-KiB LDS-DMA piece per wave; the
 // XOR swizzle of the 16-B chunk index (applied on the source side) makes the fragment reads spread
 // over the banks: bf16 transposing reads touch rows {q, 8+q} per 32-lane half, f32 reads rows {k, k+1}.
@@ -189,15 +208,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
   };
 
+#ifdef ECG_STAMP
+  unsigned long long sA = 0, sB = 0, sC = 0, t0, t1, t2, t3, tk0, tk1;
+  ECG_WSTAMP_AT(tk0);
+#endif
   if (s_begin < s_end) {
     dma(0, s_begin);
     __syncthreads();  // drains vmcnt: stage 0 has landed for every wave
     for (int step = s_begin, k = 0; step < s_end; ++step, ++k) {
+#ifdef ECG_STAMP
+      ECG_WSTAMP_AT(t0);
+#endif
       if (step + 1 < s_end) dma((k + 1) & 1, step + 1);  // buffer last read in iteration k-1, fenced by its barrier
+#ifdef ECG_STAMP
+      ECG_WSTAMP_AT(t1);
+#endif
       compute(k & 1);
+#ifdef ECG_STAMP
+      ECG_WSTAMP_AT(t2);
+#endif
       __syncthreads();
+#ifdef ECG_STAMP
+      ECG_WSTAMP_AT(t3);
+      sA += t1 - t0; sB += t2 - t1; sC += t3 - t2;
+#endif
     }
   }
+#ifdef ECG_STAMP
+  ECG_WSTAMP_AT(tk1);
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_wstamp[0], sA);
+    atomicAdd(&g_wstamp[1], sB);
+    atomicAdd(&g_wstamp[2], sC);
+    atomicAdd(&g_wstamp[4], tk1 - tk0);
+    atomicAdd(&g_wstamp[6], 1ull);
+    atomicAdd(&g_wstamp[7], (unsigned long long)(s_end - s_begin));
+  }
+#endif
 
   // ---- slab store: D[row = co][col = ci]; lane: ci = fr, co = fq*4 + j
   const int RS = NT;

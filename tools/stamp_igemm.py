@@ -31,4 +31,23 @@ for name, (H, W, Cin, Cout) in SH.items():
     tot = a + b + c
     print(f"{name}: per iteration: DMA issue {a / tot:5.1%}  frag reads + MFMA {b / tot:5.1%}  barrier (+vmcnt) {c / tot:5.1%}"
           f" | cycles/iteration {tot / wg / (9 * Cin // 64):7.0f} | K loop {kl / (kl + ep):5.1%} epilogue {ep / (kl + ep):5.1%}"
-          f" (values+sums {e1 / (kl + ep):5.1%}, swaps+stores {(ep - e1) / (kl + ep):5.1%}) | workgroups/launch {wg / n:.0f}")
+          f" (part 1 {e1 / (kl + ep):5.1%}; fast path's value/pack/swap/store loop {float(out[7]) / (kl + ep):5.1%}) | workgroups/launch {wg / n:.0f}")
+
+if "--wgrad" in sys.argv:
+    raw.ecgmm_wstamp_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    for name, (H, W, Cin, Cout) in SH.items():
+        d = L.ConvDesc(B, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+        x = torch.randn(B * H * W * Cin, device="cuda:0").to(torch.bfloat16)
+        dy = torch.randn(B * H * W * Cout, device="cuda:0").to(torch.bfloat16)
+        dw = torch.empty(Cout * Cin * 9, device="cuda:0")
+        nb = lib.ecgmm_conv_bwd_weight_workspace(L.BF16, C.byref(d))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda:0")
+        out = (C.c_ulonglong * 8)()
+        run = lambda: L.check(lib.ecgmm_conv_bwd_weight(L.BF16, C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), nb, stream()))
+        run(); torch.cuda.synchronize(); raw.ecgmm_wstamp_read(out, 1)
+        for _ in range(5): run()
+        torch.cuda.synchronize(); raw.ecgmm_wstamp_read(out, 1)
+        a, b, c, _, kl, _, wg, steps = [float(v) for v in out[:8]]
+        tot = a + b + c
+        print(f"wgrad {name}: per K step: DMA issue {a / tot:5.1%}  frag reads + MFMA {b / tot:5.1%}  barrier (+vmcnt) {c / tot:5.1%}"
+              f" | cycles/step {tot / steps:7.0f} | loop share of kernel body {tot / kl:5.1%}")
