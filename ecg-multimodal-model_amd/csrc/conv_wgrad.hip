@@ -132,17 +132,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const unsigned rem = pp - (unsigned)n * (unsigned)HW;
     const int oh = (int)(((unsigned long long)rem * p.mul_w) >> p.sh_w);
     const int ow = (int)rem - oh * p.OW;
-    wg_dma16(rs_dy, base, (pok && dy_lane != OOB) ? (unsigned)(pix - (int)pix0) * dy_row_bytes + dy_lane : OOB);
+    wg_dma16(rs_dy, base, ((int)pok & (int)(dy_lane != OOB)) ? (unsigned)(pix - (int)pix0) * dy_row_bytes + dy_lane : OOB);
     const int hb = oh * p.stride - p.pad_h, wb = ow * p.stride - p.pad_w;
     // byte offset of tap (0,0)'s source pixel, once per step; tap (r, s) is a wave-uniform delta away.  (Per tap this
     // used to be two quarter-rate 32-bit multiplies per lane plus a scalar division by S: with 9 taps per 36 MFMAs the
     // kernel was VALU- and SALU-bound, 3.6 VALU + 2.7 SALU per MFMA.)
     const unsigned off00 = (unsigned)(((n - n0) * p.H + hb) * p.W + wb) * x_pix_bytes + x_lane;
-    const bool lane_ok = pok && x_lane != OOB;
+    // (bitwise, not short-circuit: with && the compiler turned every tap's DMA into two exec-masked branches)
+    const int lane_ok = (int)pok & (int)(x_lane != OOB);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int r = s3 ? t / 3 : t, s = s3 ? t % 3 : 0;  // (t is a constant after unrolling; s3 is wave-uniform)
-      const bool ok = lane_ok && (unsigned)(hb + r) < (unsigned)p.H && (unsigned)(wb + s) < (unsigned)p.W;
+      const int ok = lane_ok & (int)((unsigned)(hb + r) < (unsigned)p.H) & (int)((unsigned)(wb + s) < (unsigned)p.W);
       wg_dma16(rs_x, base + (1 + t) * TILE_BYTES, ok ? off00 + tap_delta[t] : OOB);
     }
   };
