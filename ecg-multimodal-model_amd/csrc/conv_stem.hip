@@ -87,13 +87,20 @@ template <int R>
 __device__ __forceinline__ void stem_fetch_patch(const StemParams& p, const StemPatchIdx& ix, float (&pre)[NPRE], int n,
                                                  int oh0, int ow0) {
   const int ih0 = oh0 * 2 - p.pad_h, iw0 = ow0 * 2 - 3;
-  // (may point in front of the image; only dereferenced for in-range elements)
-  const float* base = p.x + ((size_t)n * p.Cin * p.H + ih0) * (ptrdiff_t)p.W + iw0;
+  // Buffer loads over the tile's image with an out-of-range offset for padding elements: hardware zero-fill, no
+  // branch (as a conditional global load every one of the 16 fetches was its own exec-masked branch).
+  const size_t img = (size_t)p.Cin * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * img), 0,
+                                                                      (int)(img * sizeof(float)), 0x00020000);
+  const int org = ih0 * p.W + iw0;
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) {
     const int ph = ix.hw[k] >> 16, pw = ix.hw[k] & 0xffff;
-    const bool ok = (unsigned)(ih0 + ph) < (unsigned)p.H && (unsigned)(iw0 + pw) < (unsigned)p.W;
-    pre[k] = ok ? base[ix.rel[k]] : 0.f;
+    const int ok = (int)((unsigned)(ih0 + ph) < (unsigned)p.H) & (int)((unsigned)(iw0 + pw) < (unsigned)p.W);
+    const unsigned off = ok ? (unsigned)(ix.rel[k] + org) * 4u : 0xFFFFFFFFu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    pre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+#endif
   }
 }
 template <int R>
