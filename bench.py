@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--workload", default="multimodal", choices=list(FLOP_PER_SAMPLE))
     ap.add_argument("--image-hw", default="224x224", help="image size HxW (250x2500 = the reference's full-resolution "
                     "lead image, dataset_image.py:67-70)")
+    ap.add_argument("--freeze-encoders", action="store_true", help="train.py:35-40 faithful step: the three encoders "
+                    "get no gradients (forward in train mode, backward through the heads only); not the headline number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event kernel timing")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -86,6 +88,12 @@ def build(args, device):
         def loss_fn(out, y):
             return HF.focal_loss(out, y, 1.0, 2.0)
     labels = torch.randint(0, 2, (B,), generator=g)
+    if args.freeze_encoders:
+        if args.workload != "multimodal":
+            raise SystemExit("--freeze-encoders applies to the multimodal workload (train.py:35-40)")
+        for enc in (model.image_encoder, model.signal_encoder, model.clinical_encoder):
+            for p in enc.parameters():
+                p.requires_grad = False
     model = model.to(device).train()
     batch = tuple(t.to(device) for t in batch)
     return model, batch, labels.to(device), loss_fn
@@ -162,7 +170,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     ddp = DataParallel(model, force=force_ddp) if (world > 1 or force_ddp) else None
-    opt = FusedAdam(model.parameters(), lr=1e-4, grad_scale=1.0 / world)
+    opt = FusedAdam((p for p in model.parameters() if p.requires_grad), lr=1e-4, grad_scale=1.0 / world)
 
     def step():
         opt.zero_grad()
@@ -274,6 +282,9 @@ def main():
             "roofline": roof,
             "roofline_serialized": roof_serial,
         }
+        if args.freeze_encoders:
+            out["config"]["workload"] += "; ENCODERS FROZEN as train.py:35-40 (forward + head backward only)"
+            out["config"]["frozen_encoders"] = True
         if args.serialize:
             out["config"]["serialized_streams"] = True   # profiling configuration, not the headline number
         if world == 1 and not args.no_cpu_baseline:

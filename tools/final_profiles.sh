@@ -12,4 +12,9 @@ python3 $R/tools/kstats.py $O/kts 13 60 > $O/kernel_stats_serialized.txt
 python3 $R/bench.py --workload image_only --batch 128 --no-cpu-baseline > $O/bench_cfg2.json 2>/dev/null || exit 1
 python3 $R/bench.py --workload signal12 --batch 512 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null || exit 1
 python3 $R/bench.py --image-hw 250x2500 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_f2.json 2>/dev/null || exit 1
-echo final-done
+echo final-done-main
+# SURVEY 8d extras: the train.py-faithful frozen-encoder step, and exact-fp32 runs of cfg 3 / cfg 5
+python3 $R/bench.py --freeze-encoders --no-cpu-baseline > $O/bench_cfg3_frozen.json 2>/dev/null || exit 1
+python3 $R/bench.py --dtype fp32 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg3_fp32.json 2>/dev/null || exit 1
+python3 $R/bench.py --workload signal12 --batch 512 --dtype fp32 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg5_fp32.json 2>/dev/null || exit 1
+echo extras-done
