@@ -146,6 +146,11 @@ def cpu_baseline(seconds):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL prints its version
+    # block there at communicator creation) are sent to stderr for the rest of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,7 +294,8 @@ def main():
             out["config"]["serialized_streams"] = True   # profiling configuration, not the headline number
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

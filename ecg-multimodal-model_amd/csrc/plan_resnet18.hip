@@ -194,7 +194,7 @@ struct Side {
   hipStream_t s = nullptr;
   hipEvent_t ev[32];
   int next = 0;
-  bool ok = false, enabled = true;
+  bool ok = false, enabled = true, defer_join = false;
   hipEvent_t doneA = nullptr, doneB = nullptr, doneC = nullptr;  // last reader of dy / dy1 / dyd
 };
 Side g_side;
@@ -249,6 +249,26 @@ int bn_coef(const R18& r, const float* stats, int rows, int C, long count, const
 extern "C" int ecgmm_side_wgrad(int on) {
   ECG_TRY(side_init());
   g_side.enabled = on != 0;
+  return 0;
+}
+
+// Data-parallel overlap: with defer = 1 a backward call returns WITHOUT joining the side stream to the caller's
+// stream (the dgrad chain of the next stage group then keeps overlapping this group's weight-gradient tail); the
+// caller orders its consumer (the all-reduce stream) after the weight gradients with ecgmm_side_wait() and must
+// run the last stage group with defer = 0, whose join covers everything.
+extern "C" int ecgmm_side_defer_join(int defer) {
+  ECG_TRY(side_init());
+  g_side.defer_join = defer != 0;
+  return 0;
+}
+
+// Everything the side stream has been given so far happens-before later work on `stream`.
+extern "C" int ecgmm_side_wait(void* stream) {
+  ECG_TRY(side_init());
+  if (!g_side.enabled) return 0;
+  hipEvent_t e = side_next_ev();
+  if (hipEventRecord(e, g_side.s) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, e, 0) != hipSuccess)
+    ECG_FAIL(ECGMM_ERR_LAUNCH, "side wait failed");
   return 0;
 }
 
@@ -415,7 +435,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: stage %d out of range", st);
     }
   }
-  if (side) {  // join: everything the side stream did is ordered before whatever the caller enqueues next
+  if (side && !g_side.defer_join) {  // join: everything the side stream did is ordered before whatever the caller enqueues next
     hipEvent_t e = side_next_ev();
     (void)hipEventRecord(e, g_side.s);
     (void)hipStreamWaitEvent(s, e, 0);

@@ -1,6 +1,7 @@
 """Encoder-level autograd Functions: one C-ABI call runs a whole ResNet18 / ResNet1D_SE forward (or a
 range of backward stages) as a native launch plan (csrc/plan_resnet18.hip, plan_resnet1d.hip)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -57,11 +58,21 @@ class _PlanFn(torch.autograd.Function):
         bws = _Scratch.get(spec.prefix + "_bwd", nb, dfeat.device)
         fn = getattr(lib, spec.prefix + "_backward")
         stages = spec.stage_groups or [(0, spec.n_stages)]
-        for gi, (b, e) in enumerate(stages):
-            L.check(fn(C.byref(desc), ptr(ctx.x), ptr(dfeat), ptab, gtab, ptr(ctx.ws), ptr(bws), bws.numel(), b, e,
-                       stream()), spec.name + " backward")
-            if spec.stage_hook is not None:
-                spec.stage_hook(spec, gi)
+        # with a stage hook (data-parallel overlap) only the last group joins the weight-gradient side stream to
+        # this stream; the hook orders its all-reduce after the side stream itself (ecgmm_side_wait)
+        defer = spec.stage_hook is not None and len(stages) > 1 and hasattr(lib, "ecgmm_side_defer_join") \
+            and spec.prefix == "ecgmm_resnet18" and os.environ.get("ECGMM_DDP_DEFER_JOIN", "1") != "0"
+        try:
+            for gi, (b, e) in enumerate(stages):
+                if defer:
+                    lib.ecgmm_side_defer_join(int(gi + 1 < len(stages)))
+                L.check(fn(C.byref(desc), ptr(ctx.x), ptr(dfeat), ptab, gtab, ptr(ctx.ws), ptr(bws), bws.numel(), b, e,
+                           stream()), spec.name + " backward")
+                if spec.stage_hook is not None:
+                    spec.stage_hook(spec, gi)
+        finally:
+            if defer:
+                lib.ecgmm_side_defer_join(0)
         ctx.ws = None
         return (None, None) + (None,) * len(ctx.params)
 

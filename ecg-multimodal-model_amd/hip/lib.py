@@ -44,6 +44,8 @@ SIGNATURES = {
     "ecgmm_resnet18_forward": (i32, [P(ResNet18Desc), vp, P(vp), P(vp), vp, vp, sz, vp]),
     "ecgmm_resnet18_backward": (i32, [P(ResNet18Desc), vp, vp, P(vp), P(vp), vp, vp, sz, i32, i32, vp]),
     "ecgmm_side_wgrad": (i32, [i32]),
+    "ecgmm_side_defer_join": (i32, [i32]),
+    "ecgmm_side_wait": (i32, [vp]),
     "ecgmm_resnet1d_fwd_workspace": (sz, [P(ResNet1DDesc)]),
     "ecgmm_resnet1d_bwd_workspace": (sz, [P(ResNet1DDesc)]),
     "ecgmm_resnet1d_forward": (i32, [P(ResNet1DDesc), vp, P(vp), P(vp), vp, vp, sz, vp]),

@@ -97,14 +97,19 @@ class DataParallel(torch.nn.Module):
     def _stage_hook(self, spec, gi):
         r = self._enc_ranges[gi]
         if r is not None:
-            self._launch(r[0], r[1])
+            self._launch(r[0], r[1], side=True)
             self._done_ranges.append(r)
 
-    def _launch(self, lo, hi):
+    def _launch(self, lo, hi, side=False):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ev)
+            if side:
+                # the stage's weight gradients were produced on the library's side stream, which that stage's
+                # backward call did not join to the compute stream (hip/encoders.py): wait for it here instead
+                from .hip import lib as L
+                L.check(L.lib().ecgmm_side_wait(self._comm_stream.cuda_stream), "side_wait")
             pos = lo
             while pos < hi:
                 end = min(hi, pos + self.bucket_elems)

@@ -69,6 +69,11 @@ int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float* image, co
 /* The ResNet18 backward runs its weight-gradient kernels on a library-owned side stream (forked from /
  * joined to `stream` with events inside each call).  0 = keep everything on the caller's stream. */
 int ecgmm_side_wgrad(int on);
+/* Data-parallel overlap (parallel.py): defer = 1 makes ecgmm_resnet18_backward return without joining the side
+ * stream; ecgmm_side_wait(stream) orders `stream` (the all-reduce stream) after the weight gradients issued so
+ * far.  The last stage group of a backward must run with defer = 0. */
+int ecgmm_side_defer_join(int defer);
+int ecgmm_side_wait(void* stream);
 
 #define ECGMM_RESNET1D_NPARAMS 52
 #define ECGMM_RESNET1D_NBUFFERS 27
