@@ -243,8 +243,10 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) d[j] = m[j] > 0.f ? d[j] : 0.f;
     }
-    // dz_out carries the masked gradient only (the residual-branch gradient), before gate / addc
-    if (APPLY && p.dz_out) st16((T*)p.dz_out + r * p.C + c0, pack16<T>(d));
+    // dz_out carries the masked gradient only (the residual-branch gradient), before gate / addc.  With a separate
+    // mask tensor the REDUCE pass stores it and the apply pass reads it back as its `dout` (host side below): one
+    // tensor read less than re-reading dout and the mask tensor; the values are identical (a masked copy of dout)
+    if (p.dz_out) st16((T*)p.dz_out + r * p.C + c0, pack16<T>(d));
     if (p.gate) {
       const float* gp = p.gate + (r / p.rows_per_sample) * p.C + c0;
 #pragma unroll
@@ -798,6 +800,8 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   p.dout = dout; p.maskref = maskref; p.gate = gate; p.addc = addc; p.y = y; p.coef = coef; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   p.partial = partial;
+  const bool dz_early = dy && dz_out && maskref && maskref != y && dz_out != dout;
+  if (dz_early) p.dz_out = dz_out;
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, false>(p, grid, stream)), (bn_bwd_launch<float, false>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_reduce");
   {
@@ -809,6 +813,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   ECG_CHECK_LAUNCH("bn_bwd_finalize");
   if (!dy) return 0;
   p.bcoef = bcoef; p.dy = dy; p.dz_out = dz_out;
+  if (dz_early) { p.dout = dz_out; p.maskref = nullptr; p.dz_out = nullptr; }
   p.partial = dbias ? partial : nullptr;  // reuse (finalize already consumed it; stream-ordered)
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");
