@@ -39,6 +39,9 @@ template <> struct StemCfg<float> { static constexpr int WPAD = 4; };
 template <int R> struct StemDims {
   static constexpr int TH = R == 1 ? 1 : 8, TW = R == 1 ? 128 : 16;
   static constexpr int PH = (TH - 1) * 2 + R, PW = (TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+  // patch elements a thread prefetches (registers): 2-D 3 channels x 21 x 38 = 2394 <= 10 * 256; 1-D up to 15 leads.
+  // (16 for both kept the 2-D kernels at 184 VGPRs = 2 waves per SIMD; 10 lets a third workgroup onto the CU.)
+  static constexpr int NPRE = R == 1 ? 16 : 10;
 };
 
 template <int R>
@@ -63,14 +66,13 @@ __device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patc
 // Which patch element a thread fetches does not depend on the tile, so its image-relative offset and its
 // (row, col) inside the patch are decoded ONCE per workgroup (StemPatchIdx); per tile only the origin moves
 // (the decode is ~30 VALU with quarter-rate mul_hi per element: it was most of the kernel's VALU time).
-constexpr int NPRE = 16;
-struct StemPatchIdx {
+template <int NPRE> struct StemPatchIdx {
   int rel[NPRE];  // (c * H + ph) * W + pw
   int hw[NPRE];   // ph << 16 | pw; 0x7fff7fff for slots outside the patch
 };
 template <int R>
-__device__ __forceinline__ void stem_patch_idx(const StemParams& p, StemPatchIdx& ix) {
-  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS;
+__device__ __forceinline__ void stem_patch_idx(const StemParams& p, StemPatchIdx<StemDims<R>::NPRE>& ix) {
+  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS, NPRE = StemDims<R>::NPRE;
   const int total = p.Cin * PH * PWS;
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) {
@@ -84,8 +86,9 @@ __device__ __forceinline__ void stem_patch_idx(const StemParams& p, StemPatchIdx
   }
 }
 template <int R>
-__device__ __forceinline__ void stem_fetch_patch(const StemParams& p, const StemPatchIdx& ix, float (&pre)[NPRE], int n,
-                                                 int oh0, int ow0) {
+__device__ __forceinline__ void stem_fetch_patch(const StemParams& p, const StemPatchIdx<StemDims<R>::NPRE>& ix,
+                                                 float (&pre)[StemDims<R>::NPRE], int n, int oh0, int ow0) {
+  constexpr int NPRE = StemDims<R>::NPRE;
   const int ih0 = oh0 * 2 - p.pad_h, iw0 = ow0 * 2 - 3;
   // Buffer loads over the tile's image with an out-of-range offset for padding elements: hardware zero-fill, no
   // branch (as a conditional global load every one of the 16 fetches was its own exec-masked branch).
@@ -104,7 +107,8 @@ __device__ __forceinline__ void stem_fetch_patch(const StemParams& p, const Stem
   }
 }
 template <int R>
-__device__ __forceinline__ void stem_store_patch(const StemParams& p, float* patch, const float (&pre)[NPRE]) {
+__device__ __forceinline__ void stem_store_patch(const StemParams& p, float* patch, const float (&pre)[StemDims<R>::NPRE]) {
+  constexpr int NPRE = StemDims<R>::NPRE;
   const int total = p.Cin * StemDims<R>::PH * StemDims<R>::PWS;
 #pragma unroll
   for (int k = 0; k < NPRE; ++k) {
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
   }
   const int ntiles = p.N * p.tiles_h * p.tiles_w;
-  float pre[NPRE];
-  StemPatchIdx pix;
+  float pre[StemDims<R>::NPRE];
+  StemPatchIdx<StemDims<R>::NPRE> pix;
   stem_patch_idx<R>(p, pix);
   {
     int n_, oh_, ow_;
@@ -347,9 +351,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   const T* dy = (const T*)p.y;
   constexpr int CH = 64 * (int)sizeof(T) / 16;  // 16-B chunks per dy row
   constexpr int NDY = 128 * CH / 256;           // dy vectors per thread per tile (4 bf16 / 8 f32)
-  float pre[NPRE];
+  float pre[StemDims<R>::NPRE];
   u32x4 pdy[NDY];
-  StemPatchIdx pix;
+  StemPatchIdx<StemDims<R>::NPRE> pix;
   stem_patch_idx<R>(p, pix);
   auto fetch = [&](int tile) {
     int n, oh0, ow0;
@@ -495,7 +499,7 @@ int stem_shape(int Cin, int H, int W, int R, StemShape& s) {
   s.KP = ((s.NG + 3) / 4) * 32;
   {
     int PH = (s.TH - 1) * 2 + R, PW = (s.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
-    if (Cin * PH * PWS > 16 * 256) ECG_FAIL(ECGMM_ERR_SHAPE, "stem: input patch of %d channels exceeds the prefetch registers", Cin);
+    if (Cin * PH * PWS > (R == 1 ? 16 : 10) * 256) ECG_FAIL(ECGMM_ERR_SHAPE, "stem: input patch of %d channels exceeds the prefetch registers", Cin);
   }
   return 0;
 }
