@@ -152,20 +152,27 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   float pre[StemDims<R>::NPRE];
   StemPatchIdx<StemDims<R>::NPRE> pix;
   stem_patch_idx<R>(p, pix);
+  // Two patch buffers: the next tile's patch is fetched into registers at the top of a tile and written to the
+  // OTHER buffer between this tile's MFMA loop and its epilogue, so the wait for those loads does not also wait for
+  // the previous epilogue's output stores (stores and loads share vmcnt), and a tile needs one barrier, not two.
+  float* const patch0 = patch;
+  const int patch_elems = (p.Cin * PH * PWS + 3) & ~3;
   {
     int n_, oh_, ow_;
     if ((int)blockIdx.x < ntiles) {
       stem_tile_origin(p, blockIdx.x, TH, TW, n_, oh_, ow_);
       stem_fetch_patch<R>(p, pix, pre, n_, oh_, ow_);
+      stem_store_patch<R>(p, patch0, pre);
     }
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();  // weights and the first patch staged
+  int cur = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
   int n, oh0, ow0;
   stem_tile_origin(p, tile, TH, TW, n, oh0, ow0);
-  __syncthreads();  // previous tile's patch fully consumed (and, first time, weights staged)
-  stem_store_patch<R>(p, patch, pre);
-  __syncthreads();
-  if (tile + (int)gridDim.x < ntiles) {  // next tile's patch streams in underneath this tile's MFMAs
+  patch = patch0 + cur * patch_elems;
+  const bool has_next = tile + (int)gridDim.x < ntiles;
+  if (has_next) {  // next tile's patch streams in underneath this tile's MFMAs
     int n_, oh_, ow_;
     stem_tile_origin(p, tile + gridDim.x, TH, TW, n_, oh_, ow_);
     stem_fetch_patch<R>(p, pix, pre, n_, oh_, ow_);
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }
 
   if (sizeof(T) == 2) mfma_drain();
+  if (has_next) stem_store_patch<R>(p, patch0 + (cur ^ 1) * patch_elems, pre);
   // epilogue: lane = pixel fr of tile b, channels a*16 + fq*4 + j
   T* y = (T*)p.y;
   // bf16: the 8-byte packs of neighbouring channel tiles are exchanged between lane rows (v_permlane16_swap) so every
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
       }
   }
 #endif
+  __syncthreads();  // the other buffer is complete; everyone is done reading this one
   }  // tile loop
 }
 
@@ -542,7 +551,7 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   p.x = x; p.wpk = wpk; p.y = y; p.bias = bias; p.stats = stats;
   const size_t esz = dtype_size(dtype);
   const int WS = s.KP + (dtype == ECGMM_BF16 ? 8 : 4);
-  size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + patch_bytes(s, Cin, R);
+  size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + 2 * align_up(patch_bytes(s, Cin, R), 16);  // two patch buffers
   const int ntiles = N * s.tiles_h * s.tiles_w;
   dim3 grid(ntiles < 2048 ? ntiles : 2048);  // persistent: each workgroup stages the weights once, then walks tiles
   ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7,
