@@ -117,6 +117,12 @@ __device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const u32x4& a, co
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 #endif
 }
+// first MFMA of an accumulation: C = 0 as an inline constant (no accumulator zero-fill, no zero registers)
+__device__ __forceinline__ void mfma_bf16_first(f32x4& acc, const u32x4& a, const u32x4& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+#endif
+}
 __device__ __forceinline__ void mfma_drain() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");  // >= 18 wait states: last MFMA's D -> any reader

@@ -12,6 +12,10 @@
 
 __device__ __host__ inline size_t align_up_dev(size_t a) { return (a + 15) & ~(size_t)15; }
 
+#ifndef STEM_ABL
+#define STEM_ABL 0  // diagnostic builds (tools/stem_ablate.sh): 1 no output stores, 2 no statistics, 3 no MFMA loop, 4 no patch fetch
+#endif
+
 namespace {
 
 constexpr int STEM_CO = 64;
@@ -125,21 +129,71 @@ __device__ __forceinline__ void stem_tile_origin(const StemParams& p, int tile, 
   ow0 = tw_i * TW;
 }
 
+// A workgroup keeps ONE tile position (th, tw) and walks images, so everything that depends only on the position is
+// computed once: which image-relative byte a thread fetches for patch slot k (padding and out-of-patch slots get an
+// out-of-range offset: hardware zero fill), the pixel validity and output offsets of the epilogue.  Per image only
+// the buffer base (scalar) moves.  (Walking arbitrary tiles cost ~900 VALU per wave-tile for 48 MFMAs -- two runtime
+// tile-index divisions, per-element bounds tests and 64-bit addresses; SQ counters)
+template <int R>
+__device__ __forceinline__ void stem_patch_offsets(const StemParams& p, int oh0, int ow0,
+                                                   unsigned (&off)[StemDims<R>::NPRE]) {
+  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS, NPRE = StemDims<R>::NPRE;
+  const int total = p.Cin * PH * PWS;
+  const int ih0 = oh0 * 2 - p.pad_h, iw0 = ow0 * 2 - 3;
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const int pw = i % PWS;
+    const int t = i / PWS;
+    const int ph = t % PH, c = t / PH;
+    const int ih = ih0 + ph, iw = iw0 + pw;
+    const int ok = (int)(i < total) & (int)(pw < PW) & (int)((unsigned)ih < (unsigned)p.H) &
+                   (int)((unsigned)iw < (unsigned)p.W);
+    off[k] = ok ? (unsigned)((c * p.H + ih) * p.W + iw) * 4u : 0xFFFFFFFFu;
+  }
+}
+template <int R>
+__device__ __forceinline__ void stem_fetch_image_patch(const StemParams& p, const unsigned (&off)[StemDims<R>::NPRE],
+                                                       float (&pre)[StemDims<R>::NPRE], int n) {
+  const size_t img = (size_t)p.Cin * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * img), 0,
+                                                                      (int)(img * sizeof(float)), 0x00020000);
+#pragma unroll
+  for (int k = 0; k < StemDims<R>::NPRE; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    pre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off[k], 0, 0));
+#endif
+  }
+}
+// patch buffers hold NPRE * 256 elements, so every slot is stored (the slots past the patch carry zeros).  The bf16
+// kernel keeps the patch in bf16: converted once per element here instead of once per use in the MFMA loop (an element
+// feeds ~12 operand fragments), half the LDS bytes per fragment read, and a workgroup's LDS drops to 35 KB.
+template <typename T, int R>
+__device__ __forceinline__ void stem_store_slots(T* patch, const float (&pre)[StemDims<R>::NPRE]) {
+#pragma unroll
+  for (int k = 0; k < StemDims<R>::NPRE; ++k) {
+    if constexpr (sizeof(T) == 2) patch[threadIdx.x + 256 * k] = f2bf(pre[k]);
+    else patch[threadIdx.x + 256 * k] = pre[k];
+  }
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TH = StemDims<R>::TH, TW = StemDims<R>::TW, PH = StemDims<R>::PH, PWS = StemDims<R>::PWS;
+  constexpr int NPRE = StemDims<R>::NPRE, PB = NPRE * 256;  // elements per patch buffer
   constexpr int VEC = Elem<T>::VEC;
+  constexpr int KSMAX = (MAXG + 3) / 4;  // 6 (even: offsets are kept in pairs)
   const int ksteps = (p.NG + 3) / 4;
   const int KP = ksteps * 32;
   const int WS = KP + StemCfg<T>::WPAD;  // weight row stride (elements; rows stay 16-B aligned)
   T* sW = reinterpret_cast<T*>(smem);
-  float* patch = reinterpret_cast<float*>(smem + align_up_dev((size_t)STEM_CO * WS * sizeof(T)));
+  T* const patch0 = reinterpret_cast<T*>(smem + align_up_dev((size_t)STEM_CO * WS * sizeof(T)));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
 
-  // stage the packed weights once per workgroup (16-B vectors); the workgroup then walks its tiles
+  // stage the packed weights once per workgroup (16-B vectors)
   {
     const T* wg = (const T*)p.wpk;
     const int vpr = KP / VEC;  // vectors per row
@@ -148,79 +202,92 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
       *reinterpret_cast<u32x4*>(sW + co * WS + kv * VEC) = *reinterpret_cast<const u32x4*>(wg + (size_t)co * KP + kv * VEC);
     }
   }
-  const int ntiles = p.N * p.tiles_h * p.tiles_w;
-  float pre[StemDims<R>::NPRE];
-  StemPatchIdx<StemDims<R>::NPRE> pix;
-  stem_patch_idx<R>(p, pix);
-  // Two patch buffers: the next tile's patch is fetched into registers at the top of a tile and written to the
-  // OTHER buffer between this tile's MFMA loop and its epilogue, so the wait for those loads does not also wait for
-  // the previous epilogue's output stores (stores and loads share vmcnt), and a tile needs one barrier, not two.
-  float* const patch0 = patch;
-  const int patch_elems = (p.Cin * PH * PWS + 3) & ~3;
-  {
-    int n_, oh_, ow_;
-    if ((int)blockIdx.x < ntiles) {
-      stem_tile_origin(p, blockIdx.x, TH, TW, n_, oh_, ow_);
-      stem_fetch_patch<R>(p, pix, pre, n_, oh_, ow_);
-      stem_store_patch<R>(p, patch0, pre);
-    }
-  }
-  __syncthreads();  // weights and the first patch staged
-  int cur = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
-  int n, oh0, ow0;
-  stem_tile_origin(p, tile, TH, TW, n, oh0, ow0);
-  patch = patch0 + cur * patch_elems;
-  const bool has_next = tile + (int)gridDim.x < ntiles;
-  if (has_next) {  // next tile's patch streams in underneath this tile's MFMAs
-    int n_, oh_, ow_;
-    stem_tile_origin(p, tile + gridDim.x, TH, TW, n_, oh_, ow_);
-    stem_fetch_patch<R>(p, pix, pre, n_, oh_, ow_);
-  }
+  // grid = tile positions per image x image slots
+  const int tpi = p.tiles_h * p.tiles_w;
+  const int pos = blockIdx.x % tpi, slot = blockIdx.x / tpi, nslots = gridDim.x / tpi;
+  const int th_i = pos / p.tiles_w, tw_i = pos - th_i * p.tiles_w;
+  const int oh0 = th_i * TH, ow0 = tw_i * TW;
 
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float pre[NPRE];
+  unsigned poff[NPRE];
+  stem_patch_offsets<R>(p, oh0, ow0, poff);
 
+  // this lane's two 16-pixel segments: patch offset of the pixel, validity and output offset (position constants)
   constexpr int segs = TW / 16;
-  int prow[2], pcol[2];
+  int prow[2], pcol[2], boff[2], oofs[2];
+  bool okb[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    int t = wave * 2 + b;  // 16-pixel tile index within the workgroup (8 tiles)
+    const int t = wave * 2 + b;  // 16-pixel segment index within the workgroup (8 segments)
     prow[b] = t / segs;
     pcol[b] = (t % segs) * 16 + fr;
+    boff[b] = prow[b] * 2 * PWS + pcol[b] * 2;
+    okb[b] = (oh0 + prow[b] < p.OH) & (ow0 + pcol[b] < p.OW);
+    oofs[b] = ((oh0 + prow[b]) * p.OW + ow0 + pcol[b]) * STEM_CO;
+  }
+  // patch row of this lane's (c, r) group in every k-step (padded groups carry zero weights; keep the read in bounds)
+  // (two 16-bit offsets per register: the kernel sits at the 96-VGPR edge of a fourth wave per SIMD)
+  unsigned goff2[KSMAX / 2];
+#pragma unroll
+  for (int ks = 0; ks < KSMAX; ++ks) {
+    int G = ks * 4 + fq;
+    if (G >= p.NG) G = p.NG - 1;
+    const int c = G / R, r = G - c * R;
+    const unsigned g = (unsigned)((c * PH + r) * PWS);
+    if (ks & 1) goff2[ks / 2] |= g << 16;
+    else goff2[ks / 2] = g;
+  }
+  const T* wlane = sW + fr * WS + fq * 8;  // bf16 A fragments: + a * 16 * WS + ks * 32
+
+  // Two patch buffers: the next image's patch is fetched into registers at the top of a tile and written to the
+  // OTHER buffer between this tile's MFMA loop and its epilogue, so the wait for those loads does not also wait for
+  // the previous epilogue's output stores (stores and loads share vmcnt), and a tile needs one barrier, not two.
+  int n = slot;
+  if (n < p.N) {
+    stem_fetch_image_patch<R>(p, poff, pre, n);
+    stem_store_slots<T, R>(patch0, pre);
+  }
+  __syncthreads();  // weights and the first patch staged
+  for (int cur = 0; n < p.N; n += nslots, cur ^= 1) {
+  const T* patch = patch0 + cur * PB;
+  const bool has_next = n + nslots < p.N;
+  if (has_next && (STEM_ABL != 4 || p.N < 0)) stem_fetch_image_patch<R>(p, poff, pre, n + nslots);  // streams in underneath this tile's MFMAs
+
+  f32x4 acc[4][2];
+  if constexpr (sizeof(T) != 2) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int ks = 0; ks < ksteps; ++ks) {
-    int G = ks * 4 + fq;
-    if (G >= p.NG) G = p.NG - 1;  // padded groups carry zero weights; keep the read in bounds
-    const int c = G / R, r = G - c * R;
-    float bv[2][8];
+  if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float* src = patch + (c * PH + prow[b] * 2 + r) * PWS + pcol[b] * 2;
+    for (int ks = 0; ks < KSMAX; ++ks) {
+      if (ks < ksteps && (STEM_ABL != 3 || p.N < 0)) {
+        u32x4 fb[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float2 v = *reinterpret_cast<const float2*>(src + 2 * j);
-        bv[b][2 * j] = v.x;
-        bv[b][2 * j + 1] = v.y;
+        for (int b = 0; b < 2; ++b) {
+          // 8 consecutive bf16 of one patch row; the start is only 4-byte aligned (pixel column * 2 elements)
+          const int goff = (ks & 1) ? (int)(goff2[ks / 2] >> 16) : (int)(goff2[ks / 2] & 0xffffu);
+          const unsigned* src = reinterpret_cast<const unsigned*>(patch + goff + boff[b]);
+          fb[b] = (u32x4){src[0], src[1], src[2], src[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          u32x4 fa = *reinterpret_cast<const u32x4*>(wlane + a * 16 * WS + ks * 32);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if (ks == 0) mfma_bf16_first(acc[a][b], fa, fb[b]);  // ksteps >= 1 always: C = 0 inline
+            else mfma_bf16_inplace(acc[a][b], fa, fb[b]);
+          }
+        }
       }
     }
-    if constexpr (sizeof(T) == 2) {
-      u32x4 fb[2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) fb[b] = pack16<bf16_t>(bv[b]);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        u32x4 fa = *reinterpret_cast<const u32x4*>(sW + (a * 16 + fr) * WS + ks * 32 + fq * 8);
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          mfma_bf16_inplace(acc[a][b], fa, fb[b]);
-      }
-    } else {
-      // f32: the k index of a 16x16x4 step is the lane quad; walk the 4 groups x 8 taps of this kstep
+    mfma_drain();
+  } else {
+    // f32: the k index of a 16x16x4 step is the lane quad; walk the 4 groups x 8 taps of every kstep
+    for (int ks = 0; ks < ksteps; ++ks) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         int G2 = ks * 4 + g;
@@ -231,7 +298,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
           const int s = hf * 4 + fq;
           float fbv[2];
 #pragma unroll
-          for (int b = 0; b < 2; ++b) fbv[b] = patch[(c2 * PH + prow[b] * 2 + r2) * PWS + pcol[b] * 2 + s];
+          for (int b = 0; b < 2; ++b) fbv[b] = patch[(c2 * PH + r2) * PWS + boff[b] + s];
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
             float fav = sW[(a * 16 + fr) * WS + (ks * 4 + g) * 8 + s];
@@ -244,16 +311,23 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
   }
 
-  if (sizeof(T) == 2) mfma_drain();
-  if (has_next) stem_store_patch<R>(p, patch0 + (cur ^ 1) * patch_elems, pre);
-  // epilogue: lane = pixel fr of tile b, channels a*16 + fq*4 + j
-  T* y = (T*)p.y;
+  if (has_next) stem_store_slots<T, R>(patch0 + (cur ^ 1) * PB, pre);
+  // epilogue: lane = pixel fr of segment b, channels a*16 + fq*4 + j
+  T* yimg = (T*)p.y + (size_t)n * p.OH * p.OW * STEM_CO;
+  const int tile = n * tpi + pos;
+  // bf16 output and statistics rows go through buffer stores: scalar base + 32-bit lane offset (no 64-bit address
+  // per store), and a pixel outside the image gets an out-of-range offset instead of an exec-masked branch
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)yimg, 0, (int)((size_t)p.OH * p.OW * STEM_CO * sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.stats ? p.stats + (size_t)tile * 4 * 2 * STEM_CO : nullptr), 0, p.stats ? 4 * 2 * STEM_CO * 4 : 0, 0x00020000);
   // bf16: the 8-byte packs of neighbouring channel tiles are exchanged between lane rows (v_permlane16_swap) so every
   // lane stores 16 B and an instruction writes 64 contiguous bytes per pixel (see conv_igemm.hip's epilogue)
-  uint2 opk[4][2];
-  bool ook[2] = {false, false};
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int ap = 0; ap < 4; ap += 2) {  // channel tiles in pairs: a pair's packs are swapped and stored before the next pair
+  uint2 opk[2][2];
+#pragma unroll
+  for (int a = ap; a < ap + 2; ++a) {
     const int ch0 = a * 16 + fq * 4;
     float bvv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -263,58 +337,56 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int oh = oh0 + prow[b], ow = ow0 + pcol[b];
-      if (oh < p.OH && ow < p.OW) {
-        float v[4];
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = p.bias ? acc[a][b][j] + bvv[j] : acc[a][b][j];
+      if (okb[b]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = acc[a][b][j] + bvv[j];
           s1[j] += v[j];
           s2[j] += v[j] * v[j];
         }
-        T* o = y + (((size_t)n * p.OH + oh) * p.OW + ow) * STEM_CO + ch0;
-        if (sizeof(T) == 2) {
-          opk[a][b].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          opk[a][b].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          ook[b] = true;
-        } else {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        if (sizeof(T) != 2) *reinterpret_cast<float4*>(yimg + oofs[b] + ch0) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (sizeof(T) == 2) {
+        opk[a - ap][b].x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        opk[a - ap][b].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
       }
     }
-    if (p.stats) {
+    if (p.stats && (STEM_ABL != 2 || p.N < 0)) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s1[j] = row16_sum(s1[j]);
         s2[j] = row16_sum(s2[j]);
       }
-      if (fr == 0) {
-        float* row = p.stats + (size_t)(tile * 4 + wave) * 2 * STEM_CO;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          row[ch0 + j] = s1[j];
-          row[STEM_CO + ch0 + j] = s2[j];
-        }
+#if defined(__HIP_DEVICE_COMPILE__)
+      {
+        // lanes fr == 0 hold the row sums: [wave][2][64] floats of this tile's four statistics rows
+        const unsigned so = fr == 0 ? (unsigned)((wave * 2 * STEM_CO + ch0) * 4) : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(s1[0]), __float_as_uint(s1[1]), __float_as_uint(s1[2]), __float_as_uint(s1[3])},
+                                               srs, (int)so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(s2[0]), __float_as_uint(s2[1]), __float_as_uint(s2[2]), __float_as_uint(s2[3])},
+                                               srs, (int)so, STEM_CO * 4, 0);
       }
+#endif
     }
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (sizeof(T) == 2) {
 #pragma unroll
-    for (int a = 0; a < 4; a += 2)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        auto lo = __builtin_amdgcn_permlane16_swap(opk[a][b].x, opk[a + 1][b].x, false, false);
-        auto hi = __builtin_amdgcn_permlane16_swap(opk[a][b].y, opk[a + 1][b].y, false, false);
-        const int ch = (fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4;
-        if (ook[b])
-          *reinterpret_cast<u32x4*>(y + (((size_t)n * p.OH + oh0 + prow[b]) * p.OW + ow0 + pcol[b]) * STEM_CO + ch) =
-              (u32x4){lo[0], hi[0], lo[1], hi[1]};
-      }
+    for (int b = 0; b < 2; ++b) {
+      auto lo = __builtin_amdgcn_permlane16_swap(opk[0][b].x, opk[1][b].x, false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap(opk[0][b].y, opk[1][b].y, false, false);
+      const int ch = (fq & 1) ? (ap + 1) * 16 + (fq - 1) * 4 : ap * 16 + fq * 4;
+      const unsigned yo = okb[b] ? (unsigned)(oofs[b] + ch) * 2u : 0xFFFFFFFFu;
+      if (STEM_ABL != 1 || p.N < 0)
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo[0], hi[0], lo[1], hi[1]}, yrs, (int)yo, 0, 0);
+    }
   }
 #endif
+  }  // channel-tile pairs
   __syncthreads();  // the other buffer is complete; everyone is done reading this one
-  }  // tile loop
+  }  // image loop
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -517,6 +589,7 @@ void fill_params(StemParams& p, const StemShape& s, int N, int Cin, int H, int W
   p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.OH = s.OH; p.OW = s.OW; p.R = R; p.pad_h = R / 2;
   p.TH = s.TH; p.TW = s.TW; p.tiles_h = s.tiles_h; p.tiles_w = s.tiles_w; p.NG = s.NG;
 }
+size_t stem_patch_buffer_bytes(int R, size_t esz) { return (size_t)(R == 1 ? 16 : 10) * 256 * esz; }  // NPRE * 256 slots
 size_t patch_bytes(const StemShape& s, int Cin, int R) {
   int PH = (s.TH - 1) * 2 + R, PW = (s.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
   return (size_t)Cin * PH * PWS * sizeof(float);
@@ -551,9 +624,12 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   p.x = x; p.wpk = wpk; p.y = y; p.bias = bias; p.stats = stats;
   const size_t esz = dtype_size(dtype);
   const int WS = s.KP + (dtype == ECGMM_BF16 ? 8 : 4);
-  size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + 2 * align_up(patch_bytes(s, Cin, R), 16);  // two patch buffers
-  const int ntiles = N * s.tiles_h * s.tiles_w;
-  dim3 grid(ntiles < 2048 ? ntiles : 2048);  // persistent: each workgroup stages the weights once, then walks tiles
+  size_t lds = align_up((size_t)STEM_CO * WS * esz, 16) + 2 * stem_patch_buffer_bytes(R, esz);  // two patch buffers
+  // a workgroup = one tile position x one image slot; it stages the weights once, then walks its slot's images
+  const int tpi = s.tiles_h * s.tiles_w;
+  int nslots = 2048 / tpi;
+  nslots = nslots < 1 ? 1 : (nslots > N ? N : nslots);
+  dim3 grid(tpi * nslots);
   ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7,
                  4.0 * N * Cin * H * W + (double)dtype_size(dtype) * N * s.OH * s.OW * STEM_CO, stream);
   if (dtype == ECGMM_BF16) {
