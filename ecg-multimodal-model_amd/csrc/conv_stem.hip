@@ -32,7 +32,6 @@ struct StemParams {
   int TH, TW;        // output tile (TH*TW == 128)
   int tiles_h, tiles_w;
   int NG;            // Cin * R
-  int tiles_per_split;
 };
 
 template <typename T> struct StemCfg;
@@ -47,87 +46,6 @@ template <int R> struct StemDims {
   // (16 for both kept the 2-D kernels at 184 VGPRs = 2 waves per SIMD; 10 lets a third workgroup onto the CU.)
   static constexpr int NPRE = R == 1 ? 16 : 10;
 };
-
-template <int R>
-__device__ __forceinline__ void stem_load_patch(const StemParams& p, float* patch, int n, int oh0, int ow0) {
-  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS;
-  const int total = p.Cin * PH * PWS;
-  const float* xin = p.x + (size_t)n * p.Cin * p.H * p.W;
-  for (int i = threadIdx.x; i < total; i += 256) {
-    int pw = i % PWS;
-    int t = i / PWS;
-    int ph = t % PH, c = t / PH;
-    int ih = oh0 * 2 - p.pad_h + ph, iw = ow0 * 2 - 3 + pw;
-    float v = 0.f;
-    if (pw < PW && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-      v = xin[((size_t)c * p.H + ih) * p.W + iw];
-    patch[i] = v;
-  }
-}
-
-// Split form for software pipelining: fetch the NEXT tile's patch into registers while the current
-// tile computes, write it to LDS after the barrier.  NPRE * 256 >= Cin * PH * PWS (checked on the host).
-// Which patch element a thread fetches does not depend on the tile, so its image-relative offset and its
-// (row, col) inside the patch are decoded ONCE per workgroup (StemPatchIdx); per tile only the origin moves
-// (the decode is ~30 VALU with quarter-rate mul_hi per element: it was most of the kernel's VALU time).
-template <int NPRE> struct StemPatchIdx {
-  int rel[NPRE];  // (c * H + ph) * W + pw
-  int hw[NPRE];   // ph << 16 | pw; 0x7fff7fff for slots outside the patch
-};
-template <int R>
-__device__ __forceinline__ void stem_patch_idx(const StemParams& p, StemPatchIdx<StemDims<R>::NPRE>& ix) {
-  constexpr int PH = StemDims<R>::PH, PW = StemDims<R>::PW, PWS = StemDims<R>::PWS, NPRE = StemDims<R>::NPRE;
-  const int total = p.Cin * PH * PWS;
-#pragma unroll
-  for (int k = 0; k < NPRE; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    int pw = i % PWS;
-    int t = i / PWS;
-    int ph = t % PH, c = t / PH;
-    const bool in = i < total && pw < PW;
-    ix.rel[k] = in ? (c * p.H + ph) * p.W + pw : 0;
-    ix.hw[k] = in ? (ph << 16 | pw) : 0x7fff7fff;
-  }
-}
-template <int R>
-__device__ __forceinline__ void stem_fetch_patch(const StemParams& p, const StemPatchIdx<StemDims<R>::NPRE>& ix,
-                                                 float (&pre)[StemDims<R>::NPRE], int n, int oh0, int ow0) {
-  constexpr int NPRE = StemDims<R>::NPRE;
-  const int ih0 = oh0 * 2 - p.pad_h, iw0 = ow0 * 2 - 3;
-  // Buffer loads over the tile's image with an out-of-range offset for padding elements: hardware zero-fill, no
-  // branch (as a conditional global load every one of the 16 fetches was its own exec-masked branch).
-  const size_t img = (size_t)p.Cin * p.H * p.W;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * img), 0,
-                                                                      (int)(img * sizeof(float)), 0x00020000);
-  const int org = ih0 * p.W + iw0;
-#pragma unroll
-  for (int k = 0; k < NPRE; ++k) {
-    const int ph = ix.hw[k] >> 16, pw = ix.hw[k] & 0xffff;
-    const int ok = (int)((unsigned)(ih0 + ph) < (unsigned)p.H) & (int)((unsigned)(iw0 + pw) < (unsigned)p.W);
-    const unsigned off = ok ? (unsigned)(ix.rel[k] + org) * 4u : 0xFFFFFFFFu;
-#if defined(__HIP_DEVICE_COMPILE__)
-    pre[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
-#endif
-  }
-}
-template <int R>
-__device__ __forceinline__ void stem_store_patch(const StemParams& p, float* patch, const float (&pre)[StemDims<R>::NPRE]) {
-  constexpr int NPRE = StemDims<R>::NPRE;
-  const int total = p.Cin * StemDims<R>::PH * StemDims<R>::PWS;
-#pragma unroll
-  for (int k = 0; k < NPRE; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i < total) patch[i] = pre[k];
-  }
-}
-__device__ __forceinline__ void stem_tile_origin(const StemParams& p, int tile, int TH, int TW, int& n, int& oh0, int& ow0) {
-  const int tw_i = tile % p.tiles_w;
-  tile /= p.tiles_w;
-  const int th_i = tile % p.tiles_h;
-  n = tile / p.tiles_h;
-  oh0 = th_i * TH;
-  ow0 = tw_i * TW;
-}
 
 // A workgroup keeps ONE tile position (th, tw) and walks images, so everything that depends only on the position is
 // computed once: which image-relative byte a thread fetches for patch slot k (padding and out-of-patch slots get an
@@ -405,9 +323,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int NK = p.NG * 8;
   const int ktiles = (NK + 15) / 16;
-  const int total_tiles = p.N * p.tiles_h * p.tiles_w;
-  const int t_begin = blockIdx.x * p.tiles_per_split;
-  const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+  // grid = tile positions per image x image slots: a workgroup keeps one tile position and walks its slot's images
+  // (fetch offsets and validity are position constants, see stem_fwd_kernel); its slab row is blockIdx.x
+  const int tpi = p.tiles_h * p.tiles_w;
+  const int pos = blockIdx.x % tpi, slot = blockIdx.x / tpi, nslots = gridDim.x / tpi;
+  const int th_i = pos / p.tiles_w, tw_i = pos - th_i * p.tiles_w;
+  const int oh0 = th_i * TH, ow0 = tw_i * TW;
 
   f32x4 acc[4][3];
 #pragma unroll
@@ -416,17 +337,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     for (int b = 0; b < 3; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // this lane's B column = kidx of each owned k-tile -> (c, r, s)
-  int kc[3], krr[3], ksx[3];
-  bool kok[3];
+  // (columns past NK read patch element 0: their products are never stored)
+  int koff[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    int kidx = (wave + 4 * b) * 16 + fr;
-    kok[b] = (wave + 4 * b) < ktiles && kidx < NK;
-    int kk = kok[b] ? kidx : 0;
-    int G = kk >> 3;
-    ksx[b] = kk & 7;
-    kc[b] = G / R;
-    krr[b] = G - kc[b] * R;
+    const int kidx = (wave + 4 * b) * 16 + fr;
+    const bool kok = (wave + 4 * b) < ktiles && kidx < NK;
+    const int kk = kok ? kidx : 0;
+    const int G = kk >> 3, c = G / R;
+    koff[b] = (c * PH + (G - c * R)) * PWS + (kk & 7);
   }
 
   const T* dy = (const T*)p.y;
@@ -434,36 +353,38 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   constexpr int NDY = 128 * CH / 256;           // dy vectors per thread per tile (4 bf16 / 8 f32)
   float pre[StemDims<R>::NPRE];
   u32x4 pdy[NDY];
-  StemPatchIdx<StemDims<R>::NPRE> pix;
-  stem_patch_idx<R>(p, pix);
-  auto fetch = [&](int tile) {
-    int n, oh0, ow0;
-    stem_tile_origin(p, tile, TH, TW, n, oh0, ow0);
+  unsigned poff[StemDims<R>::NPRE], dyoff[NDY];
+  stem_patch_offsets<R>(p, oh0, ow0, poff);
+#pragma unroll
+  for (int k = 0; k < NDY; ++k) {
+    const int i = tid + 256 * k;
+    const int pix = i / CH, chunk = i % CH;
+    const int oh = oh0 + pix / TW, ow = ow0 + pix % TW;
+    dyoff[k] = (oh < p.OH) & (ow < p.OW) ? (unsigned)(((oh * p.OW + ow) * STEM_CO) * (int)sizeof(T) + chunk * 16) : 0xFFFFFFFFu;
+  }
+  auto fetch = [&](int n) {
+    const size_t dimg = (size_t)p.OH * p.OW * STEM_CO;
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)n * dimg), 0,
+                                                                          (int)(dimg * sizeof(T)), 0x00020000);
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
-      const int i = tid + 256 * k;
-      int pix = i / CH, chunk = i % CH;
-      int trow = pix / TW, tcol = pix % TW;
-      int oh = oh0 + trow, ow = ow0 + tcol;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (oh < p.OH && ow < p.OW)
-        v = *reinterpret_cast<const u32x4*>(dy + (((size_t)n * p.OH + oh) * p.OW + ow) * STEM_CO +
-                                            chunk * (16 / (int)sizeof(T)));
-      pdy[k] = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+      pdy[k] = __builtin_amdgcn_raw_buffer_load_b128(drs, (int)dyoff[k], 0, 0);
+#endif
     }
-    stem_fetch_patch<R>(p, pix, pre, n, oh0, ow0);
+    stem_fetch_image_patch<R>(p, poff, pre, n);
   };
-  if (t_begin < t_end) fetch(t_begin);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  if (slot < p.N) fetch(slot);
+  for (int n = slot; n < p.N; n += nslots) {
     __syncthreads();  // previous tile's LDS fully consumed
 #pragma unroll
     for (int k = 0; k < NDY; ++k) {
       const int i = tid + 256 * k;
       *reinterpret_cast<u32x4*>(sDY + (i / CH) * DYS + (i % CH) * 16) = pdy[k];
     }
-    stem_store_patch<R>(p, patch, pre);
+    stem_store_slots<float, R>(patch, pre);
     __syncthreads();
-    if (tile + 1 < t_end) fetch(tile + 1);  // streams in underneath this tile's MFMAs
+    if (n + nslots < p.N) fetch(n + nslots);  // streams in underneath this tile's MFMAs
 
     if constexpr (sizeof(T) == 2) {
       const int q = fr >> 2, pq = fr & 3;
@@ -486,9 +407,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           float bv[8];
-          const float* src = patch + (kc[b] * PH + trow * 2 + krr[b]) * PWS + tcol0 * 2 + ksx[b];
+          const float* src = patch + koff[b] + trow * 2 * PWS + tcol0 * 2;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bv[j] = kok[b] ? src[2 * j] : 0.f;
+          for (int j = 0; j < 8; ++j) bv[j] = src[2 * j];
           u32x4 fb = pack16<bf16_t>(bv);
 #pragma unroll
           for (int a = 0; a < 4; ++a)
@@ -504,7 +425,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
         for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const float*>(sDY + pix * DYS + (a * 16 + fr) * 4);
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          float fb = kok[b] ? patch[(kc[b] * PH + trow * 2 + krr[b]) * PWS + tcol * 2 + ksx[b]] : 0.f;
+          float fb = patch[koff[b] + trow * 2 * PWS + tcol * 2];
 #pragma unroll
           for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb, acc[a][b], 0, 0, 0);
         }
@@ -652,29 +573,31 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   return 0;
 }
 
-static int stem_nsplit(int total_tiles) { return total_tiles < 1024 ? total_tiles : 1024; }
+// wgrad grid = slab rows: tile positions per image x image slots (about 1024 workgroups)
+static int stem_wgrad_grid(int N, int tpi) {
+  int nslots = 1024 / tpi;
+  nslots = nslots < 1 ? 1 : (nslots > N ? N : nslots);
+  return tpi * nslots;
+}
 
 size_t ecg_stem_wgrad_workspace(int N, int Cin, int H, int W, int R) {
   StemShape s;
   if (stem_shape(Cin, H, W, R, s)) return 0;
-  return (size_t)stem_nsplit(N * s.tiles_h * s.tiles_w) * STEM_CO * s.NG * 8 * sizeof(float);
+  return (size_t)stem_wgrad_grid(N, s.tiles_h * s.tiles_w) * STEM_CO * s.NG * 8 * sizeof(float);
 }
 
 int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int accumulate, void* workspace,
                    size_t workspace_bytes, int N, int Cin, int H, int W, int R, hipStream_t stream) {
   StemShape s;
   ECG_TRY(stem_shape(Cin, H, W, R, s));
-  const int total = N * s.tiles_h * s.tiles_w;
-  const int nsplit = stem_nsplit(total);
-  size_t need = (size_t)nsplit * STEM_CO * s.NG * 8 * sizeof(float);
+  const int grid = stem_wgrad_grid(N, s.tiles_h * s.tiles_w);
+  size_t need = (size_t)grid * STEM_CO * s.NG * 8 * sizeof(float);
   if (!workspace || workspace_bytes < need)
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "stem wgrad: workspace %zu < %zu", workspace_bytes, need);
   StemParams p;
   fill_params(p, s, N, Cin, H, W, R);
   p.x = x; p.y = const_cast<void*>(dy); p.slab = (float*)workspace;
-  p.tiles_per_split = ceil_div(total, nsplit);
-  const int grid = ceil_div(total, p.tiles_per_split);
-  size_t lds = 128 * (size_t)(dtype == ECGMM_BF16 ? 144 : 320) + patch_bytes(s, Cin, R);
+  size_t lds = 128 * (size_t)(dtype == ECGMM_BF16 ? 144 : 320) + stem_patch_buffer_bytes(R, sizeof(float));
   if (dtype != ECGMM_BF16 && dtype != ECGMM_F32) ECG_FAIL(ECGMM_ERR_DTYPE, "stem wgrad: bad dtype %d", dtype);
   ecg_prof_begin(ECG_PROF_STEM_WGRAD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7,
                  4.0 * N * Cin * H * W + (double)dtype_size(dtype) * N * s.OH * s.OW * STEM_CO, stream);
