@@ -123,29 +123,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   unsigned tap_delta[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) tap_delta[t] = (unsigned)((s3 ? t / 3 : t) * p.W + (s3 ? t % 3 : 0)) * x_pix_bytes;
-  auto dma = [&](int stage, int step) {
-    unsigned char* base = smem + stage * STAGE_BYTES + wv * 1024;
-    const int pix = step * C::KP + drow;
-    const bool pok = pix < p.M;
-    const unsigned pp = pok ? (unsigned)pix : 0u;
+  // Pixel state of this lane's DMA row.  Steps are issued strictly in order, each KP pixels after the last, so
+  // (oh, ow), the byte offset of tap (0,0)'s source pixel and the dy row offset are ADVANCED by wave-uniform
+  // constants with at most one carry per dimension, instead of being decoded from the pixel index every step (that
+  // decode was two 64-bit magic divisions and five more quarter-rate multiplies per K step: ~40 % of the step's
+  // VALU cycles, conv_wgrad DMA issue = 40 % of a K step in the s_memtime stamps).
+  const unsigned sW_b = (unsigned)p.stride * x_pix_bytes, sH_b = (unsigned)(p.stride * p.W) * x_pix_bytes;
+  const unsigned img_b = (unsigned)(p.H * p.W) * x_pix_bytes;
+  const int d_n = C::KP / HW, d_r = C::KP - d_n * HW, d_oh = d_r / p.OW, d_ow = d_r - d_oh * p.OW;  // KP pixels ahead
+  const unsigned adv = (unsigned)d_n * img_b + (unsigned)d_oh * sH_b + (unsigned)d_ow * sW_b;
+  const unsigned carry_w = sH_b - (unsigned)p.OW * sW_b;   // ow wrapped: one output row down
+  const unsigned carry_h = img_b - (unsigned)p.OH * sH_b;  // oh wrapped: next image
+  int st_oh, st_ow;
+  unsigned st_off, st_dy;
+  {
+    const int pix = s_begin * C::KP + drow;
+    const unsigned pp = pix < p.M ? (unsigned)pix : 0u;
     const int n = (int)(((unsigned long long)pp * p.mul_hw) >> p.sh_hw);
     const unsigned rem = pp - (unsigned)n * (unsigned)HW;
-    const int oh = (int)(((unsigned long long)rem * p.mul_w) >> p.sh_w);
-    const int ow = (int)rem - oh * p.OW;
-    wg_dma16(rs_dy, base, ((int)pok & (int)(dy_lane != OOB)) ? (unsigned)(pix - (int)pix0) * dy_row_bytes + dy_lane : OOB);
-    const int hb = oh * p.stride - p.pad_h, wb = ow * p.stride - p.pad_w;
-    // byte offset of tap (0,0)'s source pixel, once per step; tap (r, s) is a wave-uniform delta away.  (Per tap this
-    // used to be two quarter-rate 32-bit multiplies per lane plus a scalar division by S: with 9 taps per 36 MFMAs the
-    // kernel was VALU- and SALU-bound, 3.6 VALU + 2.7 SALU per MFMA.)
-    const unsigned off00 = (unsigned)(((n - n0) * p.H + hb) * p.W + wb) * x_pix_bytes + x_lane;
+    st_oh = (int)(((unsigned long long)rem * p.mul_w) >> p.sh_w);
+    st_ow = (int)rem - st_oh * p.OW;
+    st_off = (unsigned)(((n - n0) * p.H + st_oh * p.stride - p.pad_h) * p.W + st_ow * p.stride - p.pad_w) * x_pix_bytes + x_lane;
+    st_dy = (unsigned)(pix - (int)pix0) * dy_row_bytes + dy_lane;
+  }
+  const int lane_x = (int)(x_lane != OOB), lane_dy = (int)(dy_lane != OOB);
+  auto dma = [&](int stage, int step) {
+    unsigned char* base = smem + stage * STAGE_BYTES + wv * 1024;
+    const int pok = (int)(step * C::KP + drow < p.M);
+    wg_dma16(rs_dy, base, (pok & lane_dy) ? st_dy : OOB);
+    const int hb = __mul24(st_oh, p.stride) - p.pad_h, wb = __mul24(st_ow, p.stride) - p.pad_w;
+    // tap (r, s) is a wave-uniform delta away from tap (0,0).
     // (bitwise, not short-circuit: with && the compiler turned every tap's DMA into two exec-masked branches)
-    const int lane_ok = (int)pok & (int)(x_lane != OOB);
+    const int lane_ok = pok & lane_x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int r = s3 ? t / 3 : t, s = s3 ? t % 3 : 0;  // (t is a constant after unrolling; s3 is wave-uniform)
       const int ok = lane_ok & (int)((unsigned)(hb + r) < (unsigned)p.H) & (int)((unsigned)(wb + s) < (unsigned)p.W);
-      wg_dma16(rs_x, base + (1 + t) * TILE_BYTES, ok ? off00 + tap_delta[t] : OOB);
+      wg_dma16(rs_x, base + (1 + t) * TILE_BYTES, ok ? st_off + tap_delta[t] : OOB);
     }
+    // advance to the next step's pixel
+    st_dy += (unsigned)C::KP * dy_row_bytes;
+    st_ow += d_ow;
+    const bool cw = st_ow >= p.OW;
+    st_ow -= cw ? p.OW : 0;
+    st_oh += d_oh + (cw ? 1 : 0);
+    const bool ch = st_oh >= p.OH;
+    st_oh -= ch ? p.OH : 0;
+    st_off += adv + (cw ? carry_w : 0u) + (ch ? carry_h : 0u);
   };
 
   const int fr = lane & 15, fq = lane >> 4;
