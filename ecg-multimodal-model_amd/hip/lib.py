@@ -110,6 +110,7 @@ SIGNATURES = {
     "ecgmm_image_resize_tables": (i32, [i32, i32, i32, i32, vp, sz]),
     "ecgmm_image_transform": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, sz, P(f32), P(f32), vp]),
     "ecgmm_prof_enable": (i32, [i32]),
+    "ecgmm_prof_pause": (i32, [i32]),
     "ecgmm_prof_collect": (i32, [i32, P(f64), P(f64), P(f64), P(i64)]),
 }
 

@@ -267,6 +267,8 @@ int ecgmm_image_transform(const void* img, float* out, int B, int H, int W, int 
  * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / algorithmic
  * HBM bytes / launches.  enable(1) times every kind, enable(2) only kinds 0 and 1, enable(0) switches it off. */
 int ecgmm_prof_enable(int on);
+/* pause(1) suspends the bracketing, pause(0) resumes it; recorded launches are kept (bench.py samples steps). */
+int ecgmm_prof_pause(int paused);
 int ecgmm_prof_collect(int nkinds, double* ms, double* flops, double* bytes, int64_t* count);
 
 #ifdef __cplusplus
