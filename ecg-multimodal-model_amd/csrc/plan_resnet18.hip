@@ -300,8 +300,14 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   const int dt = r.d.dtype, N = r.d.N;
   const int stats_rows = r.d.training ? 1 : 0;
 
-  // ---- every conv weight -> compute-dtype operand layouts, one launch
+  // ---- every conv weight -> compute-dtype operand layouts, one launch.  Nothing before the first residual block
+  // needs them, so the pack (~0.1 ms, strided transposes) runs on the side stream underneath the stem convolution.
+  ECG_TRY(side_init());
+  const bool side = g_side.enabled;
+  hipEvent_t packed = nullptr;
   {
+    hipStream_t ps = side ? g_side.s : s;
+    if (side) side_fork(s);
     EcgPackItem items[ECG_PACK_MAX];
     int n = 0;
     for (int i = 0; i < 8; ++i) {
@@ -311,7 +317,8 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
       items[n++] = {P(params, k.p_conv2), b.w2f, b.w2d, k.cout, k.cout, 9};
       if (k.down) items[n++] = {P(params, k.p_dconv), b.wdf, b.wdd, k.cout, k.cin, 1};
     }
-    ECG_TRY(ecg_pack_weight_batch(dt, items, n, s));
+    ECG_TRY(ecg_pack_weight_batch(dt, items, n, ps));
+    if (side) packed = side_mark();
   }
   // ---- stem
   ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, 3, 7, s));
@@ -319,6 +326,7 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
                   buffers, 0, w.coef0, s));
   ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
+  main_wait(s, packed);  // packed weights ready (also joins the side stream: nothing of this call is left on it)
 
   const void* cur = w.p0;
   for (int i = 0; i < 8; ++i) {
