@@ -49,6 +49,8 @@ struct EcgPackItem {
   int Cout, Cin, RS;
 };
 int ecg_pack_weight_batch(int dtype, const EcgPackItem* items, int n, hipStream_t stream);
+// plan_resnet1d.hip: switches the ResNet1D_SE backward's weight-gradient side stream (ecgmm_side_wgrad toggles both plans)
+int ecg_resnet1d_side_enable(int on);
 int ecg_pack_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int Cout, int Cin, int RS,
                     hipStream_t stream);
 int ecg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, hipStream_t stream);

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "ops.h"
+#include "side_stream.h"
 
 namespace {
 
@@ -185,48 +186,12 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   w.bytes = align_up(a.off, 256);
 }
 
-// ---- side stream for the weight-gradient kernels -------------------------------------------------
-// wgrad only feeds the optimizer, so it is taken off the critical path dgrad -> BN-backward -> dgrad:
-// it runs on a library-owned HIP stream, forked from / joined to the caller's stream with events
-// (all asynchronous and capturable; every call joins before it returns, so to the caller the work is
-// still ordered on the stream it passed).  MFMA-bound wgrad overlaps the HBM-bound BN passes.
-struct Side {
-  hipStream_t s = nullptr;
-  hipEvent_t ev[32];
-  int next = 0;
-  bool ok = false, enabled = true, defer_join = false;
-  hipEvent_t doneA = nullptr, doneB = nullptr, doneC = nullptr;  // last reader of dy / dy1 / dyd
-};
-Side g_side;
-
-int side_init() {
-  if (g_side.ok) return 0;
-  const char* e = getenv("ECGMM_SIDE_WGRAD");
-  g_side.enabled = !(e && e[0] == '0');
-  if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess)
-    ECG_FAIL(ECGMM_ERR_LAUNCH, "side stream creation failed");
-  for (int i = 0; i < 32; ++i)
-    if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess)
-      ECG_FAIL(ECGMM_ERR_LAUNCH, "side event creation failed");
-  g_side.ok = true;
-  return 0;
-}
-inline hipEvent_t side_next_ev() { return g_side.ev[g_side.next++ & 31]; }
-// everything enqueued on `main` so far happens-before later work on the side stream
-inline void side_fork(hipStream_t main) {
-  hipEvent_t e = side_next_ev();
-  (void)hipEventRecord(e, main);
-  (void)hipStreamWaitEvent(g_side.s, e, 0);
-}
-inline hipEvent_t side_mark() {
-  hipEvent_t e = side_next_ev();
-  (void)hipEventRecord(e, g_side.s);
-  return e;
-}
-inline void main_wait(hipStream_t main, hipEvent_t& e) {
-  if (e) (void)hipStreamWaitEvent(main, e, 0);
-  e = nullptr;
-}
+// ---- side stream for the weight-gradient kernels (side_stream.h) ----------------------------------
+SideStream g_side;
+int side_init() { return g_side.init(); }
+inline hipEvent_t side_next_ev() { return g_side.next_ev(); }
+inline void side_fork(hipStream_t main) { g_side.fork(main); }
+inline hipEvent_t side_mark() { return g_side.mark(); }
 
 inline const float* P(const void* const* params, int i) { return (const float*)params[i]; }
 inline float* G(void* const* grads, int i) { return grads ? (float*)grads[i] : nullptr; }
@@ -249,7 +214,7 @@ int bn_coef(const R18& r, const float* stats, int rows, int C, long count, const
 extern "C" int ecgmm_side_wgrad(int on) {
   ECG_TRY(side_init());
   g_side.enabled = on != 0;
-  return 0;
+  return ecg_resnet1d_side_enable(on);
 }
 
 // Data-parallel overlap: with defer = 1 a backward call returns WITHOUT joining the side stream to the caller's
@@ -266,10 +231,7 @@ extern "C" int ecgmm_side_defer_join(int defer) {
 extern "C" int ecgmm_side_wait(void* stream) {
   ECG_TRY(side_init());
   if (!g_side.enabled) return 0;
-  hipEvent_t e = side_next_ev();
-  if (hipEventRecord(e, g_side.s) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, e, 0) != hipSuccess)
-    ECG_FAIL(ECGMM_ERR_LAUNCH, "side wait failed");
-  return 0;
+  return g_side.wait_on((hipStream_t)stream);
 }
 
 extern "C" size_t ecgmm_resnet18_fwd_workspace(const ecgmm_resnet18_desc* d) {

@@ -10,6 +10,7 @@
 //   [downsample.0.{w,b}, downsample.1.{w,b}] (layers 2,3), then classifier.1.{w,b}, classifier.4.{w,b}.
 // Buffer table (27): running_mean, running_var, num_batches_tracked per BatchNorm in the same walk.
 #include "ops.h"
+#include "side_stream.h"
 
 namespace {
 
@@ -119,7 +120,7 @@ void layout_fwd(const R1D& r, void* base, Fwd1& w) {
 }
 
 struct Bwd1 {
-  void* X[2]; void *dz, *dy, *da, *dtmp, *big0, *big1;
+  void* X[2]; void *dz, *dy, *dy1, *dyd, *da, *dtmp, *big0, *big1;
   float *dpooled, *dh1, *dfeat_h, *dg, *ds, *dh, *dm, *dbias_scratch;
   float* bn_scratch;
   void* wg_ws; size_t wg_bytes;
@@ -134,6 +135,8 @@ void layout_bwd(const R1D& r, void* base, Bwd1& w) {
   for (int i = 0; i < 2; ++i) w.X[i] = a.take_bytes(r.max_act * es);
   w.dz = a.take_bytes(r.max_act * es);
   w.dy = a.take_bytes(r.max_act * es);
+  w.dy1 = a.take_bytes(r.max_act * es);  // own buffers for the three wgrad operands: the side stream still reads one
+  w.dyd = a.take_bytes(r.max_act * es);  // while the main stream's BatchNorm backward writes the next
   w.da = a.take_bytes(r.max_act * es);
   w.dtmp = a.take_bytes(r.max_act * es);
   size_t big = (size_t)N * r.L1 * 64;
@@ -190,6 +193,14 @@ int bn_coef(const R1D& r, const float* stats, int rows, int C, long count, const
 }
 
 }  // namespace
+
+// weight-gradient side stream of this plan (side_stream.h); its own instance, see there
+static SideStream g_side1;
+int ecg_resnet1d_side_enable(int on) {
+  ECG_TRY(g_side1.init());
+  g_side1.enabled = on != 0;
+  return 0;
+}
 
 extern "C" size_t ecgmm_resnet1d_fwd_workspace(const ecgmm_resnet1d_desc* d) {
   R1D r;
@@ -292,9 +303,13 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
   if (!ws_fwd || !ws_bwd || ws_bwd_bytes < q.bytes)
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "resnet1d bwd: workspace %zu < %zu", ws_bwd_bytes, q.bytes);
   const int dt = r.d.dtype, N = r.d.N, cin = r.d.cin;
+  ECG_TRY(g_side1.init());
+  const bool side = g_side1.enabled;
+  hipStream_t wst = side ? g_side1.s : s;  // stream of the weight-gradient kernels
 
   for (int st = stage_begin; st < stage_end; ++st) {
     if (st == 0) {
+      g_side1.doneA = g_side1.doneB = g_side1.doneC = nullptr;
       const int pc = r.p_cls;
       const bool drop = r.d.dropout_p > 0.f;
       ECG_TRY(ecg_linear_bwd(dfeat, drop ? w.hd : w.h1, P(params, pc + 2), q.dfeat_h, G(grads, pc + 2),
@@ -325,33 +340,51 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
       ECG_TRY(ecg_linear_bwd(q.dh, b.m, P(params, p + 8), q.dm, G(grads, p + 8), G(grads, p + 9), N, k.cout, k.cr,
                              q.lin_ws, q.lin_bytes, s));
       ECG_TRY(ecg_axpby(1.f / (float)k.lout, q.dm, 0.f, q.dm, (long)N * k.cout, s));
+      main_wait(s, g_side1.doneA);  // the previous block's wgrad2 has finished reading q.dy
       ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, b.g, q.dm, k.lout, b.y2, b.coef2, P(params, p + 6), G(grads, p + 6),
                          G(grads, p + 7), q.dy, q.dz, G(grads, p + 5), M, k.cout, q.bn_scratch, s));
-      if (G(grads, p + 4)) ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, p + 4), 0, q.wg_ws, q.wg_bytes, s));
+      if (G(grads, p + 4)) {
+        if (side) g_side1.fork(s);
+        ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, p + 4), 0, q.wg_ws, q.wg_bytes, wst));
+        if (side) g_side1.doneA = g_side1.mark();
+      }
       ECG_TRY(ecg_conv_igemm(dt, 1, g2, q.dy, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
+      main_wait(s, g_side1.doneB);
       ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1 /* mask recomputed from y1 */, nullptr, nullptr, 1, b.y1, b.coef1, P(params, p + 2), G(grads, p + 2),
-                         G(grads, p + 3), q.dy, nullptr, G(grads, p + 1), M, k.cout, q.bn_scratch, s));
-      if (G(grads, p + 0)) ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy, G(grads, p + 0), 0, q.wg_ws, q.wg_bytes, s));
+                         G(grads, p + 3), q.dy1, nullptr, G(grads, p + 1), M, k.cout, q.bn_scratch, s));
+      if (G(grads, p + 0)) {
+        if (side) g_side1.fork(s);
+        ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy1, G(grads, p + 0), 0, q.wg_ws, q.wg_bytes, wst));
+        if (side) g_side1.doneB = g_side1.mark();
+      }
       if (k.down) {
         ConvGeom gd = make_geom(N, 1, k.lin, k.cin, k.cout, 1, 1, k.stride, 0, 0);
+        main_wait(s, g_side1.doneC);
         ECG_TRY(ecg_bn_bwd(dt, q.dz, nullptr, nullptr, nullptr, 1, b.yd, b.coefd, P(params, p + 14), G(grads, p + 14),
-                           G(grads, p + 15), q.da, nullptr, G(grads, p + 13), M, k.cout, q.bn_scratch, s));
-        if (G(grads, p + 12)) ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.da, G(grads, p + 12), 0, q.wg_ws, q.wg_bytes, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.da, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+                           G(grads, p + 15), q.dyd, nullptr, G(grads, p + 13), M, k.cout, q.bn_scratch, s));
+        if (G(grads, p + 12)) {
+          if (side) g_side1.fork(s);
+          ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.dyd, G(grads, p + 12), 0, q.wg_ws, q.wg_bytes, wst));
+          if (side) g_side1.doneC = g_side1.mark();
+        }
+        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.dyd, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
       } else {
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
       }
     } else if (st == 4) {
       const void* dp0 = q.X[3 & 1];
       ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, 1, r.L1, 64, s));
       ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 2), G(grads, 2),
                          G(grads, 3), q.big1, nullptr, G(grads, 1), (long)N * r.L1, 64, q.bn_scratch, s));
-      if (G(grads, 0))
-        ECG_TRY(ecg_stem_wgrad(dt, signal, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, cin, 1, r.d.L, 1, s));
+      if (G(grads, 0)) {
+        if (side) g_side1.fork(s);
+        ECG_TRY(ecg_stem_wgrad(dt, signal, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, cin, 1, r.d.L, 1, wst));
+      }
     } else {
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet1d bwd: stage %d out of range", st);
     }
   }
+  if (side) ECG_TRY(g_side1.wait_on(s));  // join: everything the side stream did is ordered before the caller's next work
   return 0;
 }
