@@ -144,6 +144,7 @@ struct BwdWs {
   float* dpooled;
   float* bn_scratch;
   void* wg_ws; size_t wg_bytes;
+  void* stem_ws; size_t stem_bytes;  // the stem's slab buffer (it runs on the caller's stream, concurrently with side-stream wgrads)
   void* lin_ws; size_t lin_bytes;
   size_t bytes;
 };
@@ -164,7 +165,7 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   w.big1 = a.take_bytes(big * es);
   w.dpooled = a.take<float>((size_t)N * 512);
   size_t bn = ecg_bn_bwd_scratch(r.d.dtype, (long)N * r.H1 * r.W1, 64);
-  size_t wg = ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);
+  size_t wg = 0;
   for (int i = 0; i < 8; ++i) {
     const BlockCfg& k = r.blk[i];
     size_t s = ecg_bn_bwd_scratch(r.d.dtype, (long)N * k.hout * k.wout, k.cout);
@@ -181,6 +182,8 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   w.bn_scratch = (float*)a.take_bytes(bn);
   w.wg_ws = a.take_bytes(wg);
   w.wg_bytes = wg;
+  w.stem_bytes = ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);
+  w.stem_ws = a.take_bytes(w.stem_bytes);
   w.lin_bytes = ecg_linear_bwd_scratch(N, 512, r.d.out_dim);
   w.lin_ws = a.take_bytes(w.lin_bytes);
   w.bytes = align_up(a.off, 256);
@@ -262,14 +265,10 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   const int dt = r.d.dtype, N = r.d.N;
   const int stats_rows = r.d.training ? 1 : 0;
 
-  // ---- every conv weight -> compute-dtype operand layouts, one launch.  Nothing before the first residual block
-  // needs them, so the pack (~0.1 ms, strided transposes) runs on the side stream underneath the stem convolution.
-  ECG_TRY(side_init());
-  const bool side = g_side.enabled;
-  hipEvent_t packed = nullptr;
+  // ---- every conv weight -> compute-dtype operand layouts, one launch.  (Running it on the side stream underneath
+  // the stem convolution was measured: no gain -- a cross-stream event wait costs 35-140 us of GPU-side latency on
+  // this platform, more than the 0.1 ms pack hides.)
   {
-    hipStream_t ps = side ? g_side.s : s;
-    if (side) side_fork(s);
     EcgPackItem items[ECG_PACK_MAX];
     int n = 0;
     for (int i = 0; i < 8; ++i) {
@@ -279,8 +278,7 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
       items[n++] = {P(params, k.p_conv2), b.w2f, b.w2d, k.cout, k.cout, 9};
       if (k.down) items[n++] = {P(params, k.p_dconv), b.wdf, b.wdd, k.cout, k.cin, 1};
     }
-    ECG_TRY(ecg_pack_weight_batch(dt, items, n, ps));
-    if (side) packed = side_mark();
+    ECG_TRY(ecg_pack_weight_batch(dt, items, n, s));
   }
   // ---- stem
   ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, 3, 7, s));
@@ -288,7 +286,6 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
                   buffers, 0, w.coef0, s));
   ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
-  main_wait(s, packed);  // packed weights ready (also joins the side stream: nothing of this call is left on it)
 
   const void* cur = w.p0;
   for (int i = 0; i < 8; ++i) {
@@ -398,8 +395,10 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 1), G(grads, 1),
                          G(grads, 2), q.big1, nullptr, nullptr, (long)N * r.H1 * r.W1, 64, q.bn_scratch, s));
       if (G(grads, 0)) {
-        if (side) side_fork(s);
-        ECG_TRY(ecg_stem_wgrad(dt, image, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, 3, r.d.H, r.d.W, 7, ws));
+        // the last kernel of the backward stays on the caller's stream: nothing is left there to overlap it with, it
+        // overlaps the side stream's remaining wgrads instead, and the join below then waits for an event that has
+        // usually fired already (an exposed cross-stream wait costs 35-140 us here).  Own slab buffer: q.stem_ws.
+        ECG_TRY(ecg_stem_wgrad(dt, image, q.big1, G(grads, 0), 0, q.stem_ws, q.stem_bytes, N, 3, r.d.H, r.d.W, 7, s));
       }
     } else {
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: stage %d out of range", st);

@@ -124,6 +124,7 @@ struct Bwd1 {
   float *dpooled, *dh1, *dfeat_h, *dg, *ds, *dh, *dm, *dbias_scratch;
   float* bn_scratch;
   void* wg_ws; size_t wg_bytes;
+  void* stem_ws; size_t stem_bytes;
   void* lin_ws; size_t lin_bytes;
   size_t bytes;
 };
@@ -151,7 +152,7 @@ void layout_bwd(const R1D& r, void* base, Bwd1& w) {
   w.dm = a.take<float>((size_t)N * 256);
   w.dbias_scratch = a.take<float>(256);
   size_t bn = ecg_bn_bwd_scratch(r.d.dtype, (long)N * r.L1, 64);
-  size_t wg = ecg_stem_wgrad_workspace(N, r.d.cin, 1, r.d.L, 1);
+  size_t wg = 0;
   size_t lin = ecg_linear_bwd_scratch(N, 256, 64);
   size_t l2 = ecg_linear_bwd_scratch(N, 64, r.d.num_classes);
   if (l2 > lin) lin = l2;
@@ -174,6 +175,8 @@ void layout_bwd(const R1D& r, void* base, Bwd1& w) {
   w.bn_scratch = (float*)a.take_bytes(bn);
   w.wg_ws = a.take_bytes(wg);
   w.wg_bytes = wg;
+  w.stem_bytes = ecg_stem_wgrad_workspace(N, r.d.cin, 1, r.d.L, 1);
+  w.stem_ws = a.take_bytes(w.stem_bytes);
   w.lin_ws = a.take_bytes(lin);
   w.lin_bytes = lin;
   w.bytes = align_up(a.off, 256);
@@ -377,10 +380,8 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
       ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, 1, r.L1, 64, s));
       ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 2), G(grads, 2),
                          G(grads, 3), q.big1, nullptr, G(grads, 1), (long)N * r.L1, 64, q.bn_scratch, s));
-      if (G(grads, 0)) {
-        if (side) g_side1.fork(s);
-        ECG_TRY(ecg_stem_wgrad(dt, signal, q.big1, G(grads, 0), 0, q.wg_ws, q.wg_bytes, N, cin, 1, r.d.L, 1, wst));
-      }
+      if (G(grads, 0))  // last kernel: stays on the caller's stream (own slab buffer), see plan_resnet18.hip
+        ECG_TRY(ecg_stem_wgrad(dt, signal, q.big1, G(grads, 0), 0, q.stem_ws, q.stem_bytes, N, cin, 1, r.d.L, 1, s));
     } else {
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet1d bwd: stage %d out of range", st);
     }
