@@ -157,26 +157,42 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_kernel(BnActParams p) {
   const T* y = (const T*)p.y;
   const T* res = (const T*)p.res;
   T* out = (T*)p.out;
-  for (long r = (long)blockIdx.x * rpi + r0; r < p.M; r += (long)gridDim.x * rpi) {
-    float f[VEC], g[VEC];
-    unpack16<T>(ld16(y + r * p.C + c0), f);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) f[j] = f[j] * sc[j] + sh[j];
-    if (p.gate) {
-      const float* gp = p.gate + (r / p.rows_per_sample) * p.C + c0;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] *= gp[j];
-    }
+  // two rows per iteration, all (up to four) 16-B loads issued before the first use
+  const long stride = (long)gridDim.x * rpi;
+  for (long r = (long)blockIdx.x * rpi + r0; r < p.M; r += 2 * stride) {
+    const long r2 = r + stride;
+    const bool two = r2 < p.M;
+    const long rb2 = two ? r2 : r;
+    u32x4 vy[2], vr[2];
+    vy[0] = ld16(y + r * p.C + c0);
+    vy[1] = ld16(y + rb2 * p.C + c0);
     if (res) {
-      unpack16<T>(ld16(res + r * p.C + c0), g);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] += g[j] * rs[j] + rb[j];
+      vr[0] = ld16(res + r * p.C + c0);
+      vr[1] = ld16(res + rb2 * p.C + c0);
     }
-    if (p.relu) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j], 0.f);
+    for (int u = 0; u < 2; ++u) {
+      const long rr = u ? rb2 : r;
+      float f[VEC], g[VEC];
+      unpack16<T>(vy[u], f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = f[j] * sc[j] + sh[j];
+      if (p.gate) {
+        const float* gp = p.gate + (rr / p.rows_per_sample) * p.C + c0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] *= gp[j];
+      }
+      if (res) {
+        unpack16<T>(vr[u], g);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] += g[j] * rs[j] + rb[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j], 0.f);
+      }
+      if (u == 0 || two) st16(out + rr * p.C + c0, pack16<T>(f));
     }
-    st16(out + r * p.C + c0, pack16<T>(f));
   }
 }
 
