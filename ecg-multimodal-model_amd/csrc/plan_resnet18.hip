@@ -134,9 +134,12 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
 struct BwdWs {
   void* X[2];   // gradient w.r.t. block outputs (ping-pong)
   void* dz;     // masked residual-branch gradient
-  void* dy;     // gradient w.r.t. conv2's raw output
-  void* dy1;    // gradient w.r.t. conv1's raw output (separate: the side-stream wgrad may still read dy)
-  void* dyd;    // gradient w.r.t. the downsample conv's raw output
+  // operands of the side-stream weight-gradient kernels, two of each (blocks alternate): the main stream's next
+  // BatchNorm backward then never has to wait for the previous block's wgrad to finish reading, only for the one
+  // two blocks back (an exposed cross-stream wait costs 35-140 us here, and the side stream does run behind)
+  void* dy[2];   // gradient w.r.t. conv2's raw output
+  void* dy1[2];  // gradient w.r.t. conv1's raw output
+  void* dyd[2];  // gradient w.r.t. the downsample conv's raw output
   void* da;     // gradient w.r.t. a1
   void* dtmp;   // downsample-path input gradient
   void* big0;   // stem: dz0
@@ -155,9 +158,11 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   const int N = r.d.N;
   for (int i = 0; i < 2; ++i) w.X[i] = a.take_bytes(r.max_act * es);
   w.dz = a.take_bytes(r.max_act * es);
-  w.dy = a.take_bytes(r.max_act * es);
-  w.dy1 = a.take_bytes(r.max_act * es);
-  w.dyd = a.take_bytes(r.max_act * es);
+  for (int i = 0; i < 2; ++i) {
+    w.dy[i] = a.take_bytes(r.max_act * es);
+    w.dy1[i] = a.take_bytes(r.max_act * es);
+    w.dyd[i] = a.take_bytes(r.max_act * es);
+  }
   w.da = a.take_bytes(r.max_act * es);
   w.dtmp = a.take_bytes(r.max_act * es);
   size_t big = (size_t)N * r.H1 * r.W1 * 64;
@@ -339,6 +344,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   for (int st = stage_begin; st < stage_end; ++st) {
     if (st == 0) {
       g_side.doneA = g_side.doneB = g_side.doneC = nullptr;
+      for (int a = 0; a < 3; ++a) g_side.done2[a][0] = g_side.done2[a][1] = nullptr;
       const BlockCfg& last = r.blk[7];
       ECG_TRY(ecg_linear_bwd(dfeat, w.pooled, P(params, r.p_fc), q.dpooled, G(grads, r.p_fc), G(grads, r.p_fc + 1), N,
                              512, r.d.out_dim, q.lin_ws, q.lin_bytes, s));
@@ -354,40 +360,42 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       const long M = (long)N * k.hout * k.wout;
       ConvGeom g1 = make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1);
       ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
+      const int pp = st & 1;  // which of the two dy / dy1 / dyd buffers (and their reader events) this block uses
+      void *dyb = q.dy[pp], *dy1b = q.dy1[pp], *dydb = q.dyd[pp];
       // out = relu(bn2(y2) + identity)
-      main_wait(s, g_side.doneA);  // the previous block's wgrad2 has finished reading q.dy
+      main_wait(s, g_side.done2[0][pp]);  // the wgrad2 of two blocks ago has finished reading this dy buffer
       ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, nullptr, nullptr, 1, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
-                         G(grads, k.p_bn2 + 1), q.dy, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
+                         G(grads, k.p_bn2 + 1), dyb, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
       if (G(grads, k.p_conv2)) {
         if (side) side_fork(s);
-        ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, ws));
-        if (side) g_side.doneA = side_mark();
+        ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, dyb, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, ws));
+        if (side) g_side.done2[0][pp] = side_mark();
       }
-      ECG_TRY(ecg_conv_igemm(dt, 1, g2, q.dy, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
+      ECG_TRY(ecg_conv_igemm(dt, 1, g2, dyb, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
       // a1 = relu(bn1(y1)); the mask is recomputed from y1
-      main_wait(s, g_side.doneB);
+      main_wait(s, g_side.done2[1][pp]);
       ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
-                         G(grads, k.p_bn1 + 1), q.dy1, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
+                         G(grads, k.p_bn1 + 1), dy1b, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
       if (G(grads, k.p_conv1)) {
         if (side) side_fork(s);
-        ECG_TRY(ecg_conv_wgrad(dt, g1, in, q.dy1, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, ws));
-        if (side) g_side.doneB = side_mark();
+        ECG_TRY(ecg_conv_wgrad(dt, g1, in, dy1b, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, ws));
+        if (side) g_side.done2[1][pp] = side_mark();
       }
       if (k.down) {
         ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
-        main_wait(s, g_side.doneC);
+        main_wait(s, g_side.done2[2][pp]);
         ECG_TRY(ecg_bn_bwd(dt, q.dz, nullptr, nullptr, nullptr, 1, b.yd, b.coefd, P(params, k.p_dbn),
-                           G(grads, k.p_dbn), G(grads, k.p_dbn + 1), q.dyd, nullptr, nullptr, M, k.cout, q.bn_scratch,
+                           G(grads, k.p_dbn), G(grads, k.p_dbn + 1), dydb, nullptr, nullptr, M, k.cout, q.bn_scratch,
                            s));
         if (G(grads, k.p_dconv)) {
           if (side) side_fork(s);
-          ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.dyd, G(grads, k.p_dconv), 0, q.wg_ws, q.wg_bytes, ws));
-          if (side) g_side.doneC = side_mark();
+          ECG_TRY(ecg_conv_wgrad(dt, gd, in, dydb, G(grads, k.p_dconv), 0, q.wg_ws, q.wg_bytes, ws));
+          if (side) g_side.done2[2][pp] = side_mark();
         }
-        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.dyd, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, gd, dydb, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
       } else {
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
       }
     } else if (st == 9) {
       const void* dp0 = q.X[8 & 1];

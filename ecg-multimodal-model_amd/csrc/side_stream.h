@@ -11,10 +11,11 @@
 
 struct SideStream {
   hipStream_t s = nullptr;
-  hipEvent_t ev[32];
+  hipEvent_t ev[64];
   int next = 0;
   bool ok = false, enabled = true, defer_join = false;
   hipEvent_t doneA = nullptr, doneB = nullptr, doneC = nullptr;  // last reader of dy / dy1 / dyd
+  hipEvent_t done2[3][2] = {};  // the same for plans that ping-pong those buffers between blocks
 
   int init() {
     if (ok) return 0;
@@ -22,13 +23,13 @@ struct SideStream {
     enabled = !(e && e[0] == '0');
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
       ECG_FAIL(ECGMM_ERR_LAUNCH, "side stream creation failed");
-    for (int i = 0; i < 32; ++i)
+    for (int i = 0; i < 64; ++i)
       if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
         ECG_FAIL(ECGMM_ERR_LAUNCH, "side event creation failed");
     ok = true;
     return 0;
   }
-  hipEvent_t next_ev() { return ev[next++ & 31]; }
+  hipEvent_t next_ev() { return ev[next++ & 63]; }  // (a held event is waited on within ~12 later records)
   // everything enqueued on `main` so far happens-before later work on the side stream
   void fork(hipStream_t main) {
     hipEvent_t e = next_ev();
