@@ -82,8 +82,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int wco = wave & 1, wci = wave >> 1;
   const int ci_tiles = (p.Cin + 63) / 64;
-  const int co0 = (blockIdx.x / ci_tiles) * 64, ci0 = (blockIdx.x % ci_tiles) * 64;
-  const int split = blockIdx.y;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest).  All (co, ci)
+  // tiles of one split read the same pixels of x and dy, so a split's tiles are steered onto ONE XCD (its operand
+  // range then passes through one L2 instead of eight); splits are spread over the XCDs.  Bijective when the split
+  // count is a multiple of 8 (layers 2-4: 128 / 32 / 8 splits), identity otherwise.
+  int tile_id = blockIdx.x, split = blockIdx.y;
+  if ((gridDim.y & 7) == 0 && gridDim.x > 1) {
+    const int NT_ = gridDim.x, L = blockIdx.y * NT_ + blockIdx.x;
+    const int k = L >> 3;
+    split = (L & 7) + 8 * (k / NT_);
+    tile_id = k % NT_;
+  }
+  const int co0 = (tile_id / ci_tiles) * 64, ci0 = (tile_id % ci_tiles) * 64;
   const T* __restrict__ x = (const T*)p.x;
   const T* __restrict__ dy = (const T*)p.dy;
 
