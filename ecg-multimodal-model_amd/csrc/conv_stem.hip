@@ -95,6 +95,14 @@ __device__ __forceinline__ void stem_store_slots(T* patch, const float (&pre)[St
   }
 }
 
+// XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of (slot,
+// position) ids -- neighbouring tile positions, whose input patches overlap by the filter halo, then share one L2.
+// Pure speed hint (bijective for any grid size).
+__device__ __forceinline__ int stem_xcd_order() {
+  const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -122,7 +130,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }
   // grid = tile positions per image x image slots
   const int tpi = p.tiles_h * p.tiles_w;
-  const int pos = blockIdx.x % tpi, slot = blockIdx.x / tpi, nslots = gridDim.x / tpi;
+  const int vb = stem_xcd_order();
+  const int pos = vb % tpi, slot = vb / tpi, nslots = gridDim.x / tpi;
   const int th_i = pos / p.tiles_w, tw_i = pos - th_i * p.tiles_w;
   const int oh0 = th_i * TH, ow0 = tw_i * TW;
 
@@ -326,7 +335,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   // grid = tile positions per image x image slots: a workgroup keeps one tile position and walks its slot's images
   // (fetch offsets and validity are position constants, see stem_fwd_kernel); its slab row is blockIdx.x
   const int tpi = p.tiles_h * p.tiles_w;
-  const int pos = blockIdx.x % tpi, slot = blockIdx.x / tpi, nslots = gridDim.x / tpi;
+  const int vb = stem_xcd_order();
+  const int pos = vb % tpi, slot = vb / tpi, nslots = gridDim.x / tpi;
   const int th_i = pos / p.tiles_w, tw_i = pos - th_i * p.tiles_w;
   const int oh0 = th_i * TH, ow0 = tw_i * TW;
 
