@@ -32,7 +32,8 @@ FLOP_PER_SAMPLE = {  # SURVEY 8d / BASELINE.md section 4 (algorithmic, fwd + bwd
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_F32_MFMA_TFLOPS = 157.3
-PROF_KINDS = ["conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "stem_fwd", "stem_wgrad"]
+PROF_KINDS = ["conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "stem_fwd", "stem_wgrad", "conv_igemm_f32_fwd",
+              "conv_igemm_f32_dgrad"]
 
 
 def parse():
@@ -206,7 +207,7 @@ def main():
     if prof:
         # in the timed region only the kernel class the roofline line is about is bracketed by events (an event
         # pair costs ~1 us of stream time); the untimed one-stream pass below times every conv kernel kind
-        L.check(lib.ecgmm_prof_enable(2), "prof_enable")
+        L.check(lib.ecgmm_prof_enable(2 if args.dtype == "bf16" else 3), "prof_enable")
     fence()
     t0 = time.perf_counter()
     PROF_EVERY = 4   # the event pairs bracket every 4th step of the timed region (an event pair costs ~1-2 us of
@@ -225,11 +226,13 @@ def main():
         ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
         rc = lib.ecgmm_prof_collect(nk, ms, fl, by, cnt)
         kinds = {PROF_KINDS[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": int(cnt[i])} for i in range(nk)}
-        # the implicit-GEMM kernel template (fwd + dgrad instantiations) is one kernel class
-        ig_ms = kinds["conv_igemm_fwd"]["ms"] + kinds["conv_igemm_dgrad"]["ms"]
-        ig_fl = kinds["conv_igemm_fwd"]["flops"] + kinds["conv_igemm_dgrad"]["flops"]
-        ig_n = kinds["conv_igemm_fwd"]["launches"] + kinds["conv_igemm_dgrad"]["launches"]
-        ig_by = kinds["conv_igemm_fwd"]["bytes"] + kinds["conv_igemm_dgrad"]["bytes"]
+        # the implicit-GEMM kernel template (fwd + dgrad instantiations) of the run's compute dtype is one kernel class;
+        # in a bf16 run the exact-fp32 instantiation (dense tails, priced against another MFMA peak) is listed apart
+        kf, kd = ("conv_igemm_fwd", "conv_igemm_dgrad") if args.dtype == "bf16" else ("conv_igemm_f32_fwd", "conv_igemm_f32_dgrad")
+        ig_ms = kinds[kf]["ms"] + kinds[kd]["ms"]
+        ig_fl = kinds[kf]["flops"] + kinds[kd]["flops"]
+        ig_n = kinds[kf]["launches"] + kinds[kd]["launches"]
+        ig_by = kinds[kf]["bytes"] + kinds[kd]["bytes"]
         if rc != 0 or ig_ms <= 0:
             return None
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (cannot be collected from
@@ -239,7 +242,7 @@ def main():
         if args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and os.path.exists(tpath):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"], 1)
         ach = ig_fl / (ig_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad)", "achieved": round(ach, 2), "peak": peak,
+        return {"bound": "mfma", "kernel": "igemm_kernel<%s> (conv fwd + dgrad)" % ("bf16" if args.dtype == "bf16" else "f32"), "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(ig_by / max(ig_n, 1), 1), "launches": ig_n,
                 "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4), "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),

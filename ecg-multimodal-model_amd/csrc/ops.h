@@ -95,7 +95,8 @@ int ecg_linear_bwd(const float* dz, const float* x, const float* w, float* dx, f
                    int Out, void* scratch, size_t scratch_bytes, hipStream_t s);
 
 // prof.hip
-enum { ECG_PROF_IGEMM_FWD = 0, ECG_PROF_IGEMM_DGRAD = 1, ECG_PROF_WGRAD = 2, ECG_PROF_STEM_FWD = 3, ECG_PROF_STEM_WGRAD = 4 };
+enum { ECG_PROF_IGEMM_FWD = 0, ECG_PROF_IGEMM_DGRAD = 1, ECG_PROF_WGRAD = 2, ECG_PROF_STEM_FWD = 3, ECG_PROF_STEM_WGRAD = 4,
+       ECG_PROF_IGEMM_F32_FWD = 5, ECG_PROF_IGEMM_F32_DGRAD = 6 };  // exact-fp32 instantiation (other MFMA peak): own kinds
 void ecg_prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void ecg_prof_end(hipStream_t s);
 

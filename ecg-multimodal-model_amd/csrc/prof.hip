@@ -36,10 +36,11 @@ extern "C" int ecgmm_prof_enable(int on) {
     }
     g_created = true;
   }
-  // on = 1: every kind; on = 2: only the implicit-GEMM kernel class (kinds 0, 1) -- an event pair costs ~1 us of stream
-  // time, so the timed region of bench.py brackets only the kernel its roofline line is about
+  // on = 1: every kind; on = 2: only the bf16 implicit-GEMM kernel class (kinds 0, 1); on = 3: only its exact-fp32
+  // instantiation (kinds 5, 6) -- an event pair costs ~1 us of stream time, so the timed region of bench.py brackets
+  // only the kernel its roofline line is about
   g_on = on != 0;
-  g_kinds = on == 2 ? 0x3u : ~0u;
+  g_kinds = on == 2 ? 0x3u : on == 3 ? 0x60u : ~0u;
   g_n = 0;
   g_open = -1;
   return 0;

@@ -263,9 +263,10 @@ int ecgmm_image_transform(const void* img, float* out, int B, int H, int W, int 
                           size_t table_bytes, const float* mean3, const float* std3, void* stream);
 
 /* Measurement only (no reference counterpart): HIP-event timing of the conv kernels on their launch
- * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad.  collect()
+ * stream.  kinds: 0 igemm fwd, 1 igemm dgrad, 2 wgrad, 3 stem fwd, 4 stem wgrad, 5 / 6 igemm fwd / dgrad of the exact-fp32
+ * instantiation.  collect()
  * synchronises the recorded events and returns per-kind total ms / algorithmic FLOPs / algorithmic
- * HBM bytes / launches.  enable(1) times every kind, enable(2) only kinds 0 and 1, enable(0) switches it off. */
+ * HBM bytes / launches.  enable(1) times every kind, enable(2) only kinds 0 and 1, enable(3) only kinds 5 and 6, enable(0) switches it off. */
 int ecgmm_prof_enable(int on);
 /* pause(1) suspends the bracketing, pause(0) resumes it; recorded launches are kept (bench.py samples steps). */
 int ecgmm_prof_pause(int paused);
