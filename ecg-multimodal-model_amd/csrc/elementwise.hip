@@ -621,23 +621,41 @@ struct PackBatch {
   int blk0[ECG_PACK_MAX + 1];  // first block of each tensor
   int n;
 };
+// One block = a 32 (co) x 32 (ci) tile of one tensor with all its taps, staged through LDS: the OIHW rows are read in
+// contiguous 32 * RS-float runs, and both packed layouts are written as 32 consecutive elements per (row, tap) --
+// 64-byte bf16 chunks instead of one scattered 2-byte store per element (that version spent 65 us on ResNet18's
+// 11.2 M weights, 3.6x its byte floor, at the head of every forward).
+constexpr int PACK_T = 32, PACK_RS_MAX = 9;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(PackBatch b) {
+  __shared__ float tile[PACK_T][PACK_T * PACK_RS_MAX + 1];  // [co][ci * RS + tap] (+1: conflict-free column reads)
   int t = 0;
   while (t + 1 < b.n && (int)blockIdx.x >= b.blk0[t + 1]) ++t;
   const int Cout = b.cout[t], Cin = b.cin[t], RS = b.rs[t];
   const float* __restrict__ w = b.w[t];
   T* __restrict__ fwd = (T*)b.fwd[t];
   T* __restrict__ dgr = (T*)b.dgr[t];
-  const long total = (long)Cout * Cin * RS;
-  const int nb = b.blk0[t + 1] - b.blk0[t];
-  for (long i = (long)(blockIdx.x - b.blk0[t]) * 256 + threadIdx.x; i < total; i += (long)nb * 256) {
-    int tap = (int)(i % RS);
-    long r = i / RS;
-    int ci = (int)(r % Cin), co = (int)(r / Cin);
-    float v = w[i];
-    if (fwd) Elem<T>::st(fwd + ((size_t)co * RS + tap) * Cin + ci, v);
-    if (dgr) Elem<T>::st(dgr + ((size_t)ci * RS + tap) * Cout + co, v);
+  const int ci_tiles = (Cin + PACK_T - 1) / PACK_T;
+  const int lb = blockIdx.x - b.blk0[t];
+  const int co0 = (lb / ci_tiles) * PACK_T, ci0 = (lb % ci_tiles) * PACK_T;
+  const int nci = min(PACK_T, Cin - ci0), nco = min(PACK_T, Cout - co0);
+  const int run = nci * RS;  // contiguous floats of one co row inside this tile
+  for (int i = threadIdx.x; i < nco * run; i += 256) {
+    const int co = i / run, k = i - co * run;
+    tile[co][k] = w[((size_t)(co0 + co) * Cin + ci0) * RS + k];
+  }
+  __syncthreads();
+  if (fwd) {  // fwd[co][tap][ci]: 32 consecutive ci per (co, tap)
+    for (int i = threadIdx.x; i < nco * RS * PACK_T; i += 256) {
+      const int ci = i % PACK_T, ct = i / PACK_T, tap = ct % RS, co = ct / RS;
+      if (ci < nci) Elem<T>::st(fwd + ((size_t)(co0 + co) * RS + tap) * Cin + ci0 + ci, tile[co][ci * RS + tap]);
+    }
+  }
+  if (dgr) {  // dgr[ci][tap][co]: 32 consecutive co per (ci, tap)
+    for (int i = threadIdx.x; i < nci * RS * PACK_T; i += 256) {
+      const int co = i % PACK_T, ct = i / PACK_T, tap = ct % RS, ci = ct / RS;
+      if (co < nco) Elem<T>::st(dgr + ((size_t)(ci0 + ci) * RS + tap) * Cout + co0 + co, tile[co][ci * RS + tap]);
+    }
   }
 }
 
@@ -940,8 +958,8 @@ int ecg_pack_weight_batch(int dtype, const EcgPackItem* items, int n, hipStream_
       const EcgPackItem& it = items[base + i];
       b.w[i] = it.w; b.fwd[i] = it.fwd; b.dgr[i] = it.dgrad; b.cout[i] = it.Cout; b.cin[i] = it.Cin; b.rs[i] = it.RS;
       b.blk0[i] = blocks;
-      long nb = ((long)it.Cout * it.Cin * it.RS + 2047) / 2048;  // 8 elements per thread
-      blocks += (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+      if (it.RS > 9) ECG_FAIL(ECGMM_ERR_SHAPE, "pack_weight_batch: %d taps unsupported (<= 9)", it.RS);
+      blocks += ceil_div(it.Cout, 32) * ceil_div(it.Cin, 32);  // one block per 32 x 32 (co, ci) tile
     }
     b.blk0[b.n] = blocks;
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, b),
