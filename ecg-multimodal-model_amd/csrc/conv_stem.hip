@@ -511,6 +511,8 @@ int stem_shape(int Cin, int H, int W, int R, StemShape& s) {
   s.KP = ((s.NG + 3) / 4) * 32;
   {
     int PH = (s.TH - 1) * 2 + R, PW = (s.TW - 1) * 2 + 8, PWS = (PW + 1) & ~1;
+    if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)s.OH * s.OW * STEM_CO * 4.0 >= 2147483648.0)
+      ECG_FAIL(ECGMM_ERR_SHAPE, "stem: one sample of %d x %d x %d exceeds the 2 GiB buffer-addressing range", Cin, H, W);
     if (Cin * PH * PWS > (R == 1 ? 16 : 10) * 256) ECG_FAIL(ECGMM_ERR_SHAPE, "stem: input patch of %d channels exceeds the prefetch registers", Cin);
   }
   return 0;
