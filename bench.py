@@ -30,6 +30,48 @@ FLOP_PER_SAMPLE = {  # SURVEY 8d / BASELINE.md section 4 (algorithmic, fwd + bwd
     "image_only": 10.6453e9,
     "signal12": 1.1607e9,
 }
+HBM_ACHIEVABLE_TBS = 6.29     # float4 copy on MI355X (MI355X_MICROARCH.md, HBM)
+BYTES_PER_SAMPLE_BF16 = {     # SURVEY 8d minimum-traffic model, bf16 activations (fp32: x2): conv inputs/outputs once each
+    "image224": 26.1e6, "signal1": 8.34e6, "signal12": 8.34e6 + 2 * 11 * 5000 * 4.0,
+}
+ADAM_BYTES_PER_PARAM = 28.0
+
+
+def resnet18_conv_macs(H, W):
+    """(forward MACs per sample of the 20 convs, MACs of the stem alone) for an HxW picture."""
+    def o(n, k, s, p):
+        return (n + 2 * p - k) // s + 1
+    h, w = o(H, 7, 2, 3), o(W, 7, 2, 3)
+    stem = h * w * 64 * 147
+    macs = stem
+    h, w = o(h, 3, 2, 1), o(w, 3, 2, 1)
+    cin = 64
+    for L in range(4):
+        cout = 64 << L
+        for b in range(2):
+            st = 2 if (b == 0 and L > 0) else 1
+            h2, w2 = o(h, 3, st, 1), o(w, 3, st, 1)
+            macs += h2 * w2 * cout * 9 * cin + h2 * w2 * cout * 9 * cout
+            if st != 1 or cin != cout:
+                macs += h2 * w2 * cout * cin
+            h, w, cin = h2, w2, cout
+    return macs, stem
+
+
+def flop_per_sample(workload, H, W, frozen):
+    """algorithmic FLOPs of one sample's step: fwd + dgrad + wgrad (no dgrad for the first conv of an encoder);
+    with the encoders frozen (train.py:35-40) only their forward runs."""
+    if workload == "signal12":
+        return FLOP_PER_SAMPLE["signal12"]
+    macs, stem = resnet18_conv_macs(H, W)
+    img = 2.0 * macs if frozen else 2.0 * (3 * macs - stem)
+    if workload == "image_only":
+        return img + 6 * 1024.0
+    sig_fwd_macs = 185_603_840
+    sig = 2.0 * sig_fwd_macs if frozen else 1.1114e9
+    return img + sig + 0.0018e9
+
+
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_F32_MFMA_TFLOPS = 157.3
 PROF_KINDS = ["conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "stem_fwd", "stem_wgrad", "conv_igemm_f32_fwd",
@@ -145,8 +187,38 @@ def cpu_baseline(seconds):
                       f"3x224x224 + 5000-pt + 16-dim, CE + 0.1 var_loss, Adam"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks (one per GPU) with
+    torch.distributed.run as a CHILD process -- before this process has touched the GPU, and never by exec --
+    relay rank 0's JSON line and return the child's exit code."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()      # does not initialise the GPU
+    if ndev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: {args.gpus}-rank launch failed (exit {proc.returncode}, {len(lines)} result lines)\n")
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; "
+                         "pass --gpus equal to --nproc-per-node")
     # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL prints its version
     # block there at communicator creation) are sent to stderr for the rest of the run
     sys.stdout.flush()
@@ -209,16 +281,25 @@ def main():
         # pair costs ~1 us of stream time); the untimed one-stream pass below times every conv kernel kind
         L.check(lib.ecgmm_prof_enable(2 if args.dtype == "bf16" else 3), "prof_enable")
     fence()
-    t0 = time.perf_counter()
     PROF_EVERY = 4   # the event pairs bracket every 4th step of the timed region (an event pair costs ~1-2 us of
     n_sampled = 0    # stream time, ~70 pairs per step: sampling keeps their cost in `value` under 1 %)
+    # whole-step hipEvent timing: one event per step boundary on the compute stream (every side stream has been
+    # joined to it by the step's last kernel, the fused Adam)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    step_ev[0].record()
     for i in range(args.steps):
         if prof:
             lib.ecgmm_prof_pause(int(i % PROF_EVERY != 0))
             n_sampled += int(i % PROF_EVERY == 0)
         loss = step()
+        step_ev[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
+
+    def pct(q):
+        return round(step_ms[min(len(step_ms) - 1, int(q * (len(step_ms) - 1) + 0.5))], 3)
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
 
     def collect_roofline(nsteps, note):
@@ -236,9 +317,9 @@ def main():
         if rc != 0 or ig_ms <= 0:
             return None
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (cannot be collected from
-        # inside the process): tools/roofline_traffic.py -> profiles/r01_igemm_traffic.json
+        # inside the process): tools/final_profiles.sh -> profiles/r02_igemm_traffic.json (round-end code)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_igemm_traffic.json")
         if args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and os.path.exists(tpath):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"], 1)
         ach = ig_fl / (ig_ms * 1e-3) / 1e12
@@ -280,6 +361,15 @@ def main():
     if rank == 0:
         total = args.batch * world * args.steps
         value = total / elapsed
+        IH, IW = (int(v) for v in args.image_hw.lower().split("x"))
+        flop_s = flop_per_sample(args.workload, IH, IW, args.freeze_encoders)
+        esz = 1.0 if args.dtype == "bf16" else 2.0
+        img_b = BYTES_PER_SAMPLE_BF16["image224"] * (IH * IW) / (224.0 * 224.0) * esz
+        bytes_s = {"multimodal": img_b + BYTES_PER_SAMPLE_BF16["signal1"] * esz, "image_only": img_b,
+                   "signal12": BYTES_PER_SAMPLE_BF16["signal12"] * esz}[args.workload]
+        if args.freeze_encoders:
+            bytes_s *= 4.666 / 13.046      # forward share of the minimum-traffic model
+        adam_bytes = ADAM_BYTES_PER_PARAM * sum(p.numel() for p in model.parameters() if p.requires_grad)
         out = {
             "metric": "samples/sec fwd+bwd, batch-256 multimodal (img+sig+clin), 1->8 MI355X",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -291,10 +381,20 @@ def main():
                                     "signal12": "12-lead ResNet1D_SE (train_signal_12_af.py), focal loss, fwd+bwd+Adam"}[args.workload],
                        "image_hw": args.image_hw, "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 5)},
-            "mfma_roofline_frac_whole_step": round(value / world * FLOP_PER_SAMPLE[args.workload] /
-                                                   ((PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS) * 1e12), 4),
-            "roofline": roof,
-            "roofline_serialized": roof_serial,
+            "step_ms_hipevent": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(step_ms[0], 3),
+                                 "max": round(step_ms[-1], 3), "n": len(step_ms)},
+            # both whole-step fractions (the bf16 conv stack sits at the ridge): algorithmic FLOPs and
+            # algorithmic (minimum-traffic) HBM bytes of one step over the measured step time
+            "mfma_roofline_frac_whole_step": round(value / world * flop_s / (peak * 1e12), 4),
+            "hbm_roofline_frac_whole_step": round((value / world * bytes_s + adam_bytes / (elapsed / args.steps)) /
+                                                  (HBM_ACHIEVABLE_TBS * 1e12), 4),
+            "flop_per_sample": flop_s, "algorithmic_bytes_per_sample": bytes_s,
+            # `roofline`: the dominant kernel class, every launch ALONE on the GPU (extra untimed pass of this run with
+            # the stream overlap off): its avg_launch_ms is what rocprofv3 --kernel-trace reports for
+            # `bench.py --serialize`.  `roofline_timed_region`: the same launches bracketed inside the timed region,
+            # where an event pair also spans the time a launch waits for CUs held by the other streams (lower bracket)
+            "roofline": roof_serial if roof_serial is not None else roof,
+            "roofline_timed_region": roof,
         }
         if args.freeze_encoders:
             out["config"]["workload"] += "; ENCODERS FROZEN as train.py:35-40 (forward + head backward only)"

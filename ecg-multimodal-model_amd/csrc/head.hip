@@ -335,7 +335,11 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(z[c] - m);
-    float ce = (m + logf(se)) - z[labels[b]];
+    // a label outside [0, C) never indexes memory: its sample's loss is NaN, so the step's loss is NaN (loud);
+    // torch raises IndexError there -- CELossFn does too under ECGMM_CHECK_LABELS=1 (a host sync per call)
+    const long long lb = labels[b];
+    const float zl = (lb >= 0 && lb < C) ? z[lb] : __builtin_nanf("");
+    float ce = (m + logf(se)) - zl;
     float li = ce, dc = 1.f;
     if (focal) {
       float pt = expf(-ce), om = 1.f - pt;

@@ -103,9 +103,22 @@ class DeviceInputPipeline:
         from .image_transform import image_transform
         from .preprocess import preprocess_signal
         picture, signal, clinical, label, index = batch
-        picture = picture.to(self.device, non_blocking=True)
         signal = signal.to(self.device, non_blocking=True)
-        image = image_transform(picture, self.size if self.resize else None)
+        if isinstance(picture, (list, tuple)):
+            # pictures of several sizes in one batch (collate_raw): the reference resizes per sample before its
+            # collate (dataset.py:119-123), here every size bucket is one kernel launch into the common output
+            if not self.resize:
+                raise ValueError("pictures of different sizes cannot be batched without Resize (dataset_image.py:67-70)")
+            image = torch.empty(len(picture), 3, *self.size, dtype=torch.float32, device=self.device)
+            buckets = {}
+            for i, pic in enumerate(picture):
+                buckets.setdefault(tuple(pic.shape), []).append(i)
+            for idxs in buckets.values():
+                grp = torch.stack([picture[i] for i in idxs]).to(self.device, non_blocking=True)
+                image[torch.as_tensor(idxs, device=self.device)] = image_transform(grp, self.size)
+        else:
+            picture = picture.to(self.device, non_blocking=True)
+            image = image_transform(picture, self.size if self.resize else None)
         signal = preprocess_signal(signal, scaler_mean=self.mean, scaler_scale=self.scale)
         return (image, signal, clinical.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True),
                 index)
@@ -148,6 +161,16 @@ class DeviceLoader:
         for t in out[:4]:
             t.record_stream(cur)
         return out
+
+
+def collate_raw(items):
+    """default collate, except that decoded pictures of different sizes stay a list (DeviceInputPipeline resizes
+    them per size bucket; the reference's per-sample Resize accepts such data, dataset.py:119-123)"""
+    from torch.utils.data import default_collate
+    pics = [it[0] for it in items]
+    rest = default_collate([tuple(it[1:]) for it in items])
+    same = all(p.shape == pics[0].shape for p in pics)
+    return (torch.stack(pics) if same else pics, *rest)
 
 
 def _read_table(path):
@@ -230,9 +253,9 @@ def get_dataloaders(config):
                 DataLoader(ds[2], batch_size=bs, shuffle=False, num_workers=nw))
     sets, ecg_scaler, _ = build_file_datasets(config)
     pipe = DeviceInputPipeline(config, ecg_scaler)
-    raw = (DataLoader(sets[0], batch_size=bs, shuffle=True, num_workers=nw, pin_memory=True),
-           DataLoader(sets[1], batch_size=bs, shuffle=False, num_workers=nw, pin_memory=True),
-           DataLoader(sets[2], batch_size=bs, shuffle=False, num_workers=nw, pin_memory=True))
+    raw = (DataLoader(sets[0], batch_size=bs, shuffle=True, num_workers=nw, pin_memory=True, collate_fn=collate_raw),
+           DataLoader(sets[1], batch_size=bs, shuffle=False, num_workers=nw, pin_memory=True, collate_fn=collate_raw),
+           DataLoader(sets[2], batch_size=bs, shuffle=False, num_workers=nw, pin_memory=True, collate_fn=collate_raw))
     return tuple(DeviceLoader(r, pipe) for r in raw)
 
 
@@ -248,5 +271,6 @@ def get_testloader(config, test_indices=None):
     clinical_scaler = StandardScaler().fit(clinical_df[clinical_df["index"].isin(test_indices)][CLINICAL_NUMERIC_COLS])
     ds = ECGMultimodalDataset(test_indices, labels_df, ecg_signals, clinical_df, ecg_scaler, clinical_scaler,
                               _Transform(config))
-    loader = DataLoader(ds, batch_size=config.batch_size, shuffle=False, num_workers=getattr(config, "num_workers", 0))
+    loader = DataLoader(ds, batch_size=config.batch_size, shuffle=False, num_workers=getattr(config, "num_workers", 0),
+                        collate_fn=collate_raw)
     return DeviceLoader(loader, DeviceInputPipeline(config, ecg_scaler))

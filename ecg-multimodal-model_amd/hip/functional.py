@@ -14,6 +14,9 @@ import torch
 from . import lib as L
 
 vp = C.c_void_p
+# debug switch: validate class indices on the host before the loss kernels (costs a device sync per call; without it an
+# out-of-range label makes the loss NaN instead of raising like torch's CrossEntropyLoss)
+_CHECK_LABELS = __import__("os").environ.get("ECGMM_CHECK_LABELS", "0") == "1"
 
 
 def _require_cuda(t, what):
@@ -37,15 +40,39 @@ def f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def grad_sink(p):
+def grad_sink(p, accumulate=False):
     """The tensor the kernels write ``p``'s gradient into (allocated on first use, or the view of a
-    flat gradient buffer installed by ``parallel.flatten``).  None when ``p`` is frozen."""
+    flat gradient buffer installed by ``parallel.flatten``).  None when ``p`` is frozen.
+
+    A backward pass OVERWRITES the sink.  Writing the same sink twice before the optimizer has consumed
+    it (``FusedAdam.step()`` / ``zero_grad()``, ``module.zero_grad()`` or :func:`release_grads`) would
+    silently drop the first gradient -- gradient accumulation over several backward passes, or a
+    parameter used twice in one forward -- so that raises instead.  ``accumulate=True`` is for callers
+    that add into the sink themselves (TabNet's shared layers)."""
     if p is None or not p.requires_grad:
         return None
     if p.grad is None:
         view = getattr(p, "_ecg_grad_view", None)
-        p.grad = view if view is not None else torch.empty_like(p, memory_format=torch.contiguous_format)
+        p.grad = view if view is not None else torch.zeros_like(p, memory_format=torch.contiguous_format)
+        p._ecg_dirty = False
+    if getattr(p, "_ecg_dirty", False) and not accumulate:
+        raise RuntimeError(
+            "gradient sink written twice: backward passes of this library OVERWRITE .grad (train.py:65-81 pattern: "
+            "zero_grad -> backward -> step).  Call optimizer.zero_grad() / optimizer.step() (or "
+            "ecgmm.hip.functional.release_grads(model)) between backward passes; gradient accumulation and "
+            f"parameters shared by several layers are not supported (parameter shape {tuple(p.shape)})")
+    p._ecg_dirty = True
+    p._ecg_written = True
     return p.grad
+
+
+def release_grads(params):
+    """Mark the gradients of ``params`` (an iterable of parameters or a module) as consumed: the next backward
+    may overwrite them.  What ``FusedAdam.zero_grad()`` / ``step()`` do for their own parameters."""
+    if isinstance(params, torch.nn.Module):
+        params = params.parameters()
+    for p in params:
+        p._ecg_dirty = False
 
 
 def new_bytes(n, device):
@@ -217,6 +244,10 @@ class CELossFn(torch.autograd.Function):
         logits = f32c(logits)
         labels = labels.to(torch.int64).contiguous()
         B, Cn = logits.shape
+        if labels.shape != (B,):
+            raise ValueError(f"cross_entropy: expected {B} class indices, got shape {tuple(labels.shape)}")
+        if _CHECK_LABELS and B > 0 and (int(labels.min()) < 0 or int(labels.max()) >= Cn):
+            raise IndexError(f"Target {int(labels.max() if labels.max() >= Cn else labels.min())} is out of bounds.")
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         dcoef = torch.empty(B, device=logits.device, dtype=torch.float32)
         L.check(L.lib().ecgmm_ce_fwd(ptr(logits), ptr(labels), B, Cn, int(focal), float(alpha), float(gamma),

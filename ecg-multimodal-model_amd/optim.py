@@ -19,11 +19,14 @@ class FusedAdam(torch.optim.Optimizer):
         self._runs = None
 
     def zero_grad(self, set_to_none=False):
-        """Backward OVERWRITES gradients (hip/functional.py), so there is nothing to clear; the
-        gradient buffers are kept so they stay views of the flat all-reduce buffer."""
-        if set_to_none:
-            for g in self.param_groups:
-                for p in g["params"]:
+        """Backward OVERWRITES gradients (hip/functional.py), so nothing is cleared here: the buffers are kept
+        (they stay views of the flat all-reduce buffer) and marked consumed, so the next backward may write
+        them.  A parameter that the next backward does NOT write is zeroed by ``step()`` (torch's
+        ``zero_grad(set_to_none=False)`` semantics), never updated from a stale gradient."""
+        for g in self.param_groups:
+            for p in g["params"]:
+                p._ecg_dirty = False
+                if set_to_none:
                     p.grad = None
 
     def _build_runs(self):
@@ -31,14 +34,16 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             cur = None
             for p in group["params"]:
-                if not p.requires_grad:
-                    continue
+                if not p.requires_grad or p.grad is None:
+                    continue   # no gradient yet: skipped like torch.optim.Adam does (never created here)
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdam: parameters must be contiguous fp32")
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                g = HF.grad_sink(p)
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    raise RuntimeError("FusedAdam: gradients must be contiguous fp32")
                 n = p.numel()
                 gap = p.data_ptr() - cur["p_end"] if cur is not None else -1
                 # flatten() pads tensors to 16 B: a gap of <= 12 B inside the flat buffers is padding whose
@@ -63,6 +68,9 @@ class FusedAdam(torch.optim.Optimizer):
     def _runs_valid(self):
         if self._runs is None:
             return False
+        n_with_grad = sum(1 for g in self.param_groups for p in g["params"] if p.requires_grad and p.grad is not None)
+        if n_with_grad != sum(len(r["params"]) for r in self._runs):
+            return False   # a parameter gained (or lost) its gradient since the runs were planned
         for r in self._runs:
             for p, off in zip(r["params"], r["offs"]):
                 if p.grad is None or p.data_ptr() != r["p"] + off * 4 or p.grad.data_ptr() != r["g"] + off * 4:
@@ -91,6 +99,13 @@ class FusedAdam(torch.optim.Optimizer):
                             r["m"][off:off + n].copy_(prev[id(p)][0])
                             r["v"][off:off + n].copy_(prev[id(p)][1])
                             r["step"] = prev[id(p)][2]
+        # a gradient buffer that some earlier backward wrote but the one since the last zero_grad()/step() did
+        # not holds a stale value: zero it (what torch's zero_grad(set_to_none=False) would have left there)
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None and not getattr(p, "_ecg_dirty", True) and getattr(p, "_ecg_written", False):
+                    p.grad.zero_()
+                    p._ecg_written = False
         lib = L.lib()
         s = HF.stream()
         for r in self._runs:
@@ -102,6 +117,9 @@ class FusedAdam(torch.optim.Optimizer):
                                    float(self.grad_scale), s), "adam")
             for p in r["params"]:
                 self.state[p]["step"] = r["step"]
+        for g in self.param_groups:
+            for p in g["params"]:
+                p._ecg_dirty = False    # consumed: the next backward may overwrite
         return loss
 
 

@@ -249,7 +249,7 @@ class _AccLinearFn(torch.autograd.Function):
         Out = w.shape[0]
         lib = L.lib()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        sink = grad_sink(w)
+        sink = grad_sink(w, accumulate=mod._seen > 0)   # first use of a step overwrites (and is guarded), later uses add
         tmp = torch.empty_like(w) if sink is not None else None
         scratch = _Scratch.get("linear", lib.ecgmm_linear_bwd_scratch(B, In, Out), x.device)
         L.check(lib.ecgmm_linear_bwd(ptr(f32c(dy)), ptr(x), ptr(w), ptr(dx), ptr(tmp), None, B, In, Out, ptr(scratch),

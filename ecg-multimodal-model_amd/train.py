@@ -1,4 +1,6 @@
-"""Multimodal training entry point (reference: train.py:22-336 / train_paper_modal_balance.py).
+"""Multimodal training entry point (reference: train.py:22-336; ``train_paper_modal_balance`` wraps it for the
+paper_modal_balance model).  Like the reference's train.py:14 it builds ``multimodal.ECGMultimodalModel`` (TabNet
+clinical branch, widths 512 / 128 / 32) unless another ``model_cls`` is passed.
 
 Reproduces the reference loop: seed 42; encoders frozen by default as train.py:35-40 does (pass
 ``freeze_encoders=False`` for the end-to-end step of train_kfold.py:42); Adam(lr=Config.lr) on the
@@ -18,7 +20,7 @@ import torch
 from .config import Config
 from .dataset import get_dataloaders
 from .hip import functional as HF
-from .multimodal_paper_modal_balance import ECGMultimodalModel
+from .multimodal import ECGMultimodalModel      # train.py:14
 from .optim import FusedAdam
 
 
@@ -81,14 +83,16 @@ def evaluate(model, loader, device):
     return {"accuracy": acc, "f1": f1, "auc": auc}
 
 
-def main(config=Config, freeze_encoders=True, num_epochs=None, quiet=False):
+def main(config=Config, freeze_encoders=True, num_epochs=None, quiet=False, model_cls=None):
     torch.manual_seed(config.seed)
     HF.manual_seed(config.seed)
     device = torch.device(config.device)
     if not quiet:
         print(f"Using device: {device}")
+    model = (model_cls or ECGMultimodalModel)(config).to(device)
+    if getattr(config, "synthetic", True):   # synthetic batches carry the clinical width the model expects
+        config = type(config.__name__, (config,), {"clinical_input_dim": model.get_clinical_feature_dim()})
     train_loader, val_loader, test_loader = get_dataloaders(config)
-    model = ECGMultimodalModel(config).to(device)
 
     if freeze_encoders:  # train.py:35-40
         for enc in (model.image_encoder, model.signal_encoder, model.clinical_encoder):
@@ -118,9 +122,9 @@ def main(config=Config, freeze_encoders=True, num_epochs=None, quiet=False):
             for name, v in zip(("Image", "Signal", "Clinical"), w.tolist()):
                 writer.add_scalar(f"AttentionWeights/{name}", v, epoch)
         torch.save(model.state_dict(), os.path.join(ckpt_dir, "last.pth"))
-        torch.save(model.state_dict(), os.path.join(ckpt_dir, f"epoch{epoch + 1}.pth"))
-        if va_loss < min_val:
+        if va_loss < min_val:   # train.py:145-151: epochN.pth and best.pth only on improvement
             min_val, early, lr_ctr = va_loss, 0, 0
+            torch.save(model.state_dict(), os.path.join(ckpt_dir, f"epoch{epoch + 1}.pth"))
             torch.save(model.state_dict(), os.path.join(ckpt_dir, "best.pth"))
         else:
             early += 1

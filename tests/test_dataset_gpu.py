@@ -44,10 +44,34 @@ def test_device_loader_matches_reference_pipeline(tmp_path, resize):
     assert seen == len(val.dataset) + len(test.dataset)
 
 
+def test_device_loader_buckets_pictures_of_different_sizes(tmp_path):
+    """two JPEG sizes inside one batch: the reference's per-sample Resize accepts that (dataset.py:119-123)"""
+    import os
+    from PIL import Image
+    from oracle import image_ref as IR
+    ids = DR.write_tiny_dataset(str(tmp_path), n=20, sig_len=600, hw=(120, 900))
+    for i in ids[:-1:2]:                        # every other subject gets a picture of another size
+        path = os.path.join(str(tmp_path), "images", str(i), f"{str(i).zfill(3)}ECG_lead2.jpg")
+        Image.fromarray(IR.synthetic_ecg_picture(90, 1100, i + 100), "RGB").save(path, quality=90)
+    cfg = _cfg(tmp_path, resize_images=True)
+    _, val, test = D.get_dataloaders(cfg)
+    out_hw, seen, sizes = (cfg.img_height, cfg.img_width), 0, set()
+    for loader in (val, test):
+        for bi, (image, signal, clinical, label, index) in enumerate(loader):
+            torch.cuda.synchronize()
+            assert image.shape[1:] == (3, *out_hw)
+            for j in range(image.shape[0]):
+                ri, _, _, rl, rx = DR.reference_item(loader.dataset, bi * cfg.batch_size + j, out_hw)
+                sizes.add(Image.open(loader.dataset.image_path(rx)).size)
+                assert int(index[j]) == rx and int(label[j]) == rl and np.array_equal(image[j].cpu().numpy(), ri)
+                seen += 1
+    assert seen == len(val.dataset) + len(test.dataset) and len(sizes) == 2
+
+
 def test_training_entry_point_runs_on_files(tmp_path):
-    from ecgmm import train
+    from ecgmm import train_paper_modal_balance as train
     DR.write_tiny_dataset(str(tmp_path), n=28, sig_len=1000, hw=(100, 1000))
     cfg = _cfg(tmp_path, num_epochs=2)
-    history, results, _ = train.main(cfg, freeze_encoders=False, num_epochs=2, quiet=True)
+    history, results, _ = train.main(cfg, num_epochs=2, quiet=True)
     assert set(results["last"]) == {"accuracy", "f1", "auc"} and len(history) == 2
     assert np.isfinite(history[-1]["train_loss"])

@@ -179,3 +179,31 @@ def test_fused_adam_run_planning_cpu():
     opt2 = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
     opt2._build_runs()
     assert len(opt2._runs) == 1 and opt2._runs[0]["params"][0] is net[0].bias
+
+
+def test_bench_gpus_flag_launches_ranks_or_fails_loudly():
+    """`bench.py --gpus N` must never silently run one rank: without a launcher environment it spawns N
+    ranks itself (here: refuses, no GPUs), and under a launcher it insists on --gpus == WORLD_SIZE."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_fused_adam_never_creates_gradients_cpu():
+    """torch.optim.Adam skips parameters whose grad is None; FusedAdam's run planning must too (pointer logic only)."""
+    from ecgmm.optim import FusedAdam
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+    net[0].weight.grad = torch.zeros_like(net[0].weight)
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    opt._build_runs()
+    assert [len(r["params"]) for r in opt._runs] == [1] and opt._runs[0]["params"][0] is net[0].weight
+    assert all(p.grad is None for p in list(net.parameters())[1:])
+    assert opt._runs_valid()
+    net[1].bias.grad = torch.zeros_like(net[1].bias)        # a parameter gains its gradient later: runs are re-planned
+    assert not opt._runs_valid()

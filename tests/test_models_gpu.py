@@ -299,12 +299,16 @@ def test_entry_points_run_on_gpu(tmp_path, monkeypatch):
     cfg.signal_length, cfg.clinical_input_dim = 1000, 16
     cfg.synthetic_train_size, cfg.synthetic_val_size, cfg.synthetic_test_size, cfg.batch_size = 16, 8, 8, 8
     cfg.device, cfg.compute_dtype, cfg.checkpoint_dir = "cuda", "bf16", str(tmp_path / "ck")
-    hist, results, ckpt = T.main(cfg, freeze_encoders=True, num_epochs=2, quiet=True)
-    assert len(hist) == 2 and {"best", "last"} <= set(results) and 0.0 <= results["last"]["accuracy"] <= 1.0
+    import ecgmm.train_paper_modal_balance as TP
     import os
-    assert {"last.pth", "best.pth", "epoch1.pth"} <= set(os.listdir(ckpt))
-    sd = torch.load(os.path.join(ckpt, "last.pth"), map_location="cpu")
-    assert "image_encoder.layer4.1.bn2.running_var" in sd and "attention_fusion.weights" in sd
+    for main, tabnet in ((lambda: T.main(cfg, freeze_encoders=True, num_epochs=2, quiet=True), True),     # train.py:14,35-40
+                         (lambda: TP.main(cfg, num_epochs=2, quiet=True), False)):   # train_paper_modal_balance.py:13,29
+        hist, results, ckpt = main()
+        assert len(hist) == 2 and {"best", "last"} <= set(results) and 0.0 <= results["last"]["accuracy"] <= 1.0
+        assert {"last.pth", "best.pth", "epoch1.pth"} <= set(os.listdir(ckpt))
+        sd = torch.load(os.path.join(ckpt, "last.pth"), map_location="cpu")
+        assert "image_encoder.layer4.1.bn2.running_var" in sd and "attention_fusion.weights" in sd
+        assert any(k.startswith("clinical_encoder.tabnet") for k in sd) == tabnet
     for k in ("img_height", "img_width", "synthetic_train_size", "synthetic_val_size", "synthetic_test_size", "batch_size",
               "checkpoint_dir", "device"):
         monkeypatch.setattr(TI.Config, k, getattr(cfg, k), raising=False)
@@ -332,3 +336,42 @@ def test_multimodal_full_resolution_lead_image_train_step_vs_oracle():
               "image_encoder.layer4.1.conv2.weight", "fusion_classifier.0.weight"):
         g_ref = dict(ref.named_parameters())[k].grad
         assert rel_err(dict(net.named_parameters())[k].grad.cpu(), g_ref) < 2e-2, k   # 4M-term fp32 sums, B=2 BatchNorm
+
+
+def test_adam_skips_parameters_without_gradient_and_sinks_refuse_double_writes():
+    """train.py:78 puts only fusion_logits (+ var_loss) in the loss: the three branch classifiers get no gradient and
+    torch.optim.Adam leaves them at their initial values (they must not be updated from uninitialised
+    memory).  And a second backward into unconsumed sinks raises instead of silently dropping the first gradient."""
+    from ecgmm.optim import FusedAdam
+    ref, net = _build_pair("fp32")
+    net.train()
+    heads = {k: p.detach().clone() for k, p in net.named_parameters() if "_classifier." in k and "fusion" not in k}
+    assert len(heads) == 6
+    opt = FusedAdam(net.parameters(), lr=1e-2)
+    img, sig, clin, lab = (dev(t) for t in fill.synthetic_batch(8, salt=31))
+    for _ in range(3):
+        opt.zero_grad()
+        out = net(img, sig, clin)
+        (HF.cross_entropy(out[3], lab) + 0.1 * out[4]).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    for k, v in heads.items():
+        assert params[k].grad is None and torch.equal(params[k].detach(), v), k
+    assert not torch.equal(params["fusion_classifier.0.weight"].detach().cpu(),
+                           dict(ref.named_parameters())["fusion_classifier.0.weight"].detach())
+    # a gradient written by an earlier backward but not by the current one is zeroed, not re-applied
+    opt.zero_grad()
+    out = net(img, sig, clin)
+    HF.cross_entropy(out[0], lab).backward()          # image branch only: fusion head gets nothing this time
+    before = params["fusion_classifier.3.bias"].grad.clone()
+    assert before.abs().sum() > 0
+    opt.step()
+    assert params["fusion_classifier.3.bias"].grad.abs().sum() == 0
+    # double write without zero_grad()/step() in between
+    out = net(img, sig, clin)
+    loss = HF.cross_entropy(out[3], lab)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="gradient sink written twice"):
+        loss.backward()
+    HF.release_grads(net)

@@ -52,6 +52,7 @@ def test_stage_hooked_backward_equals_plain_backward(cd):
         assert ddp.overlap and model.image_encoder._spec.stage_hook is not None
         for _ in range(2):                       # second pass: the side-stream events are reused across steps
             ddp.flat_g.zero_()
+            HF.release_grads(model)              # what optimizer.zero_grad() does between backward passes
             ddp.prepare_backward()
             out = model(img, sig, clin)
             (HF.cross_entropy(out[3], lab) + 0.1 * out[4]).backward()
@@ -63,3 +64,22 @@ def test_stage_hooked_backward_equals_plain_backward(cd):
         model.image_encoder._spec.stage_groups = None
         if created:
             dist.destroy_process_group()
+
+
+def test_two_ranks_rccl_average_of_shard_gradients_and_identical_parameters():
+    """The real multi-rank path: 2 processes, one per GPU, RCCL all-reduce (tests/ddp_rank_worker.py holds the checks).
+    Needs two GPUs: skipped on the one-GPU boxes; the world-size-2 logic itself also runs on CPU under gloo
+    (tests/test_host_cpu.py)."""
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_rank_worker.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ddp2 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
