@@ -585,7 +585,11 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
                                       : (mode == 0 ? ECG_PROF_IGEMM_FWD : ECG_PROF_IGEMM_DGRAD),
                    conv_flops(g), bytes, stream);
   }
-  int rc = dtype == ECGMM_BF16 ? launch_T<bf16_t>(p, mode, stream) : launch_T<float>(p, mode, stream);
+  int rc;
+  if (ecg_conv_halo_ok(dtype, mode, g))  // stride-1 3x3 / 1x3 on whole 256-pixel tiles: halo-resident kernel (conv_halo.hip)
+    rc = ecg_conv_halo(mode, g, src, wpk, dst, bias, addend, stats, act, stream);
+  else
+    rc = dtype == ECGMM_BF16 ? launch_T<bf16_t>(p, mode, stream) : launch_T<float>(p, mode, stream);
   ecg_prof_end(stream);
   return rc;
 }

@@ -6,6 +6,10 @@
 int ecg_conv_stats_rows(long M);
 int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst,
                    const float* bias, const void* addend, float* stats, int act, hipStream_t stream);
+// conv_halo.hip: stride-1 "same" 3x3 / 1x3 convolutions with a halo-resident activation tile (bf16, whole 256-pixel tiles)
+bool ecg_conv_halo_ok(int dtype, int mode, const ConvGeom& g);
+int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst, const float* bias,
+                  const void* addend, float* stats, int act, hipStream_t stream);
 // conv_wgrad.hip
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g);
 int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, float* grad_oihw, int accumulate,

@@ -53,7 +53,7 @@ class _PlanFn(torch.autograd.Function):
         lib = L.lib()
         dfeat = f32c(dfeat)
         ptab = _table(ctx.params)
-        gtab = _table([grad_sink(p) for p in ctx.params])
+        gtab = _table([grad_sink(p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(ctx.params)])
         nb = getattr(lib, spec.prefix + "_bwd_workspace")(C.byref(desc))
         bws = _Scratch.get(spec.prefix + "_bwd", nb, dfeat.device)
         fn = getattr(lib, spec.prefix + "_backward")

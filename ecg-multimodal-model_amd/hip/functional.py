@@ -125,7 +125,9 @@ class LinearFn(torch.autograd.Function):
         else:
             dz = dy
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw, db = grad_sink(weight), grad_sink(bias)
+        # sinks only for the gradients this backward was asked for (torch.autograd.grad w.r.t. inputs leaves .grad alone)
+        dw = grad_sink(weight) if ctx.needs_input_grad[1] else None
+        db = grad_sink(bias) if ctx.needs_input_grad[2] else None
         nb = L.lib().ecgmm_linear_bwd_scratch(B, In, Out)
         scratch = _Scratch.get("linear", nb, x.device)
         L.check(L.lib().ecgmm_linear_bwd(ptr(dz), ptr(x), ptr(weight), ptr(dx), ptr(dw), ptr(db), B, In, Out,
@@ -184,8 +186,10 @@ class LayerNormFn(torch.autograd.Function):
         darr = (vp * 3)(*[ptr(d) for d in dsegs] + [None] * (3 - len(segs)))
         scratch = _Scratch.get("ln", L.lib().ecgmm_layernorm_bwd_scratch(B, D), dout.device)
         L.check(L.lib().ecgmm_layernorm_bwd(arr, dims, len(segs), ptr(fusion_w), ptr(gamma), ptr(stat), ptr(dout),
-                                            darr, 0, ptr(grad_sink(gamma)), ptr(grad_sink(beta)),
-                                            ptr(grad_sink(fusion_w)), B, ptr(scratch), stream()), "layernorm_bwd")
+                                            darr, 0, ptr(grad_sink(gamma) if ctx.needs_input_grad[0] else None),
+                                            ptr(grad_sink(beta) if ctx.needs_input_grad[1] else None),
+                                            ptr(grad_sink(fusion_w) if ctx.needs_input_grad[2] else None), B, ptr(scratch),
+                                            stream()), "layernorm_bwd")
         return (None, None, None, None, *dsegs)
 
 
@@ -367,7 +371,8 @@ class BatchNorm1dFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         scratch = _Scratch.get("bn1d", lib.ecgmm_bn_bwd_scratch(L.F32, B, Cn), x.device)
         L.check(lib.ecgmm_bn_bwd(L.F32, ptr(dy), ptr(y) if ctx.relu else None, None, None, 1, ptr(x), ptr(coef),
-                                 ptr(gamma), ptr(grad_sink(gamma)), ptr(grad_sink(beta)), ptr(dx), None, None, B, Cn,
+                                 ptr(gamma), ptr(grad_sink(gamma) if ctx.needs_input_grad[1] else None),
+                                 ptr(grad_sink(beta) if ctx.needs_input_grad[2] else None), ptr(dx), None, None, B, Cn,
                                  ptr(scratch), stream()), "bn_bwd")
         return dx, None, None, None, None, None, None, None, None, None
 

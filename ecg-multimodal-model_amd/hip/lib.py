@@ -43,6 +43,7 @@ SIGNATURES = {
     "ecgmm_resnet18_bwd_workspace": (sz, [P(ResNet18Desc)]),
     "ecgmm_resnet18_forward": (i32, [P(ResNet18Desc), vp, P(vp), P(vp), vp, vp, sz, vp]),
     "ecgmm_resnet18_backward": (i32, [P(ResNet18Desc), vp, vp, P(vp), P(vp), vp, vp, sz, i32, i32, vp]),
+    "ecgmm_conv_halo_enable": (i32, [i32]),
     "ecgmm_side_wgrad": (i32, [i32]),
     "ecgmm_side_defer_join": (i32, [i32]),
     "ecgmm_side_wait": (i32, [vp]),

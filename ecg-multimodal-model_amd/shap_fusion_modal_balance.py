@@ -57,15 +57,24 @@ def expected_gradients(fusion_model, background, x, nsamples=64, seed=0):
     bi = torch.randint(0, background.shape[0], (nsamples, B), generator=g)
     alpha = torch.rand(nsamples, B, 1, generator=g).to(x.device)
     out = None
-    for k in range(nsamples):
-        base = background[bi[k].to(background.device)].to(x.device)
-        point = (base + alpha[k] * (x - base)).detach().requires_grad_(True)
-        logits = fusion_model(point)
-        if out is None:
-            out = torch.zeros(B, D, logits.shape[1], device=x.device)
-        for c in range(logits.shape[1]):
-            grad, = torch.autograd.grad(logits[:, c].sum(), point, retain_graph=c + 1 < logits.shape[1])
-            out[:, :, c] += grad * (x - base)
+    # attributions need d logits / d input only: freeze the wrapped model for the duration, so that the HIP ops
+    # neither compute weight gradients nor touch the parameters' .grad sinks (hip/functional.py grad_sink)
+    frozen = [p for p in fusion_model.parameters() if p.requires_grad]
+    for p in frozen:
+        p.requires_grad_(False)
+    try:
+        for k in range(nsamples):
+            base = background[bi[k].to(background.device)].to(x.device)
+            point = (base + alpha[k] * (x - base)).detach().requires_grad_(True)
+            logits = fusion_model(point)
+            if out is None:
+                out = torch.zeros(B, D, logits.shape[1], device=x.device)
+            for c in range(logits.shape[1]):
+                grad, = torch.autograd.grad(logits[:, c].sum(), point, retain_graph=c + 1 < logits.shape[1])
+                out[:, :, c] += grad * (x - base)
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
     return (out / nsamples).float()
 
 

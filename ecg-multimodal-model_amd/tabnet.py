@@ -207,7 +207,8 @@ class _GhostBN(torch.autograd.Function):
         lib = L.lib()
         Cn = x.shape[1]
         dx = torch.empty_like(x)
-        dg, db = grad_sink(gamma), grad_sink(beta)
+        dg = grad_sink(gamma) if ctx.needs_input_grad[1] else None
+        db = grad_sink(beta) if ctx.needs_input_grad[2] else None
         for k, (i0, i1) in enumerate(ctx.bounds):      # parameter gradients add up over the virtual batches
             L.check(lib.ecgmm_bn_small_bwd(ptr(x[i0:i1]), ptr(dy[i0:i1]), ptr(gamma), ptr(save[k]), ptr(dx[i0:i1]), ptr(dg),
                                            ptr(db), i1 - i0, Cn, int(k > 0), stream()), "bn_small_bwd")

@@ -116,6 +116,10 @@ int ecgmm_pack_conv_weight(int dtype, const float* w_oihw, void* fwd, void* dgra
 /* nn.Conv2d / nn.Conv1d forward (F.conv2d inside torchvision BasicBlock; PMB:71,74,81 Conv1d).
  * stats (nullable): partial BatchNorm sums, ecgmm_conv_stats_rows(N*OH*OW) rows of [2][Cout]. */
 int ecgmm_conv_stats_rows(int64_t out_pixels);
+/* Stride-1 3x3 (pad 1) and 1x3 (pad 1) bf16 convolutions over whole 256-pixel tiles are served by the halo-resident
+ * kernel (csrc/conv_halo.hip) instead of the general implicit-GEMM one: mode 0 = never, 1 = for the shapes it is
+ * faster on (default), 2 = wherever it is applicable (A/B timing, tests).  Start-up value: ECGMM_CONV_HALO=0|1|2. */
+int ecgmm_conv_halo_enable(int on);
 int ecgmm_conv_fwd(int dtype, const ecgmm_conv_desc* c, const void* x, const void* w_fwd, const float* bias, void* y,
                    float* stats, int act, void* stream);
 /* autograd of the above: input gradient (addend, nullable, is added to dx) and weight gradient */

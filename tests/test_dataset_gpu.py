@@ -49,7 +49,7 @@ def test_device_loader_buckets_pictures_of_different_sizes(tmp_path):
     import os
     from PIL import Image
     from oracle import image_ref as IR
-    ids = DR.write_tiny_dataset(str(tmp_path), n=20, sig_len=600, hw=(120, 900))
+    ids = DR.write_tiny_dataset(str(tmp_path), n=28, sig_len=600, hw=(120, 900))
     for i in ids[:-1:2]:                        # every other subject gets a picture of another size
         path = os.path.join(str(tmp_path), "images", str(i), f"{str(i).zfill(3)}ECG_lead2.jpg")
         Image.fromarray(IR.synthetic_ecg_picture(90, 1100, i + 100), "RGB").save(path, quality=90)

@@ -31,6 +31,15 @@ CONV_CASES = [
     (6, 1, 300, 64, 64, 1, 3, 1, 0, 1),
     (2, 20, 17, 32, 48, 3, 3, 1, 1, 1),
     (16, 48, 48, 64, 64, 3, 3, 1, 1, 1),
+    # conv_halo.hip (bf16, stride-1 3x3 / 1x3, whole 256-pixel tiles): one tile with 16 images inside, one slice / several
+    # slices, both channel-tile widths (forward and dgrad swap Cin / Cout), layer-2 geometry (W = 28), layer-4 geometry
+    (16, 4, 4, 64, 64, 3, 3, 1, 1, 1),
+    (4, 8, 8, 64, 128, 3, 3, 1, 1, 1),
+    (8, 16, 16, 128, 256, 3, 3, 1, 1, 1),
+    (16, 28, 28, 128, 128, 3, 3, 1, 1, 1),
+    (256, 7, 7, 192, 128, 3, 3, 1, 1, 1),
+    (8, 1, 160, 64, 64, 1, 3, 1, 0, 1),
+    (4, 1, 320, 128, 256, 1, 3, 1, 0, 1),
 ]
 
 
@@ -38,9 +47,17 @@ def _conv_ref(x, w, b, stride, ph, pw):
     return F.conv2d(x, w, b, stride=stride, padding=(ph, pw))
 
 
+@pytest.fixture
+def halo_everywhere():
+    """conv_halo.hip for every shape it can serve (the default only picks it where it is the faster kernel)"""
+    L.lib().ecgmm_conv_halo_enable(2)
+    yield
+    L.lib().ecgmm_conv_halo_enable(1)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
-def test_conv_fwd_dgrad_wgrad(case, dt):
+def test_conv_fwd_dgrad_wgrad(case, dt, halo_everywhere):
     N, H, W, Cin, Cout, R, S, st, ph, pw = case
     lib = L.lib()
     x = fill.hash_tensor((N, Cin, H, W), 11)
@@ -96,6 +113,32 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     L.check(lib.ecgmm_conv_bwd_weight(dt, C.byref(d), ptr(xg), ptr(dyg), ptr(dw), 1, ptr(ws), nb, stream()))
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), 2 * w.grad) < 3e-5
+
+
+def test_conv_halo_kernel_agrees_with_the_general_kernel():
+    """same launch through both bf16 kernels (ecgmm_conv_halo_enable): identical products, other fp32 summation order"""
+    lib = L.lib()
+    N, H, W, Cin, Cout = 8, 16, 16, 128, 128
+    d = conv_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    x = to_nhwc(bf16_round(fill.hash_tensor((N, Cin, H, W), 41)), L.BF16)
+    wf, wd = pack_weight(bf16_round(fill.hash_tensor((Cout, Cin, 3, 3), 42, 0.05)), L.BF16)
+    M = N * H * W
+    outs = []
+    try:
+        for on in (2, 0):
+            lib.ecgmm_conv_halo_enable(on)
+            y = torch.empty(M * Cout, device=DEV, dtype=torch.bfloat16)
+            dx = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+            st = torch.zeros(lib.ecgmm_conv_stats_rows(M), 2, Cout, device=DEV)
+            L.check(lib.ecgmm_conv_fwd(L.BF16, C.byref(d), ptr(x), ptr(wf), None, ptr(y), ptr(st), 1, stream()))
+            L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(y), ptr(wd), ptr(x), ptr(dx), stream()))
+            torch.cuda.synchronize()
+            outs.append((y.float().cpu(), dx.float().cpu(), st.sum(0).cpu()))
+    finally:
+        lib.ecgmm_conv_halo_enable(1)
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 3e-3          # bf16 output rounding of differently ordered fp32 sums
+    assert (outs[0][0] >= 0).all()           # act = ReLU in the epilogue
 
 
 def test_conv_rejects_bad_shapes():

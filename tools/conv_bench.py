@@ -14,6 +14,7 @@ ap.add_argument("--layers", default="")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--no-stats", action="store_true", help="forward without the fused BatchNorm partial sums")
 ap.add_argument("--lib", default="", help="A/B: path of another build of libecgmm_hip.so")
+ap.add_argument("--halo", type=int, default=-1, help="conv_halo.hip: 0 never, 1 where faster (default), 2 wherever applicable")
 a = ap.parse_args()
 if a.lib:
     L.LIB_PATH = a.lib
@@ -28,6 +29,8 @@ SHAPES = [  # name, H, W, Cin, Cout, R, S, stride, ph, pw
     ("s2.k3", 1, 625, 128, 128, 1, 3, 1, 0, 1), ("s3.k3", 1, 313, 256, 256, 1, 3, 1, 0, 1),
 ]
 lib = L.lib()
+if a.halo >= 0:
+    lib.ecgmm_conv_halo_enable(a.halo)
 dev = torch.device("cuda:0")
 sel = set(a.layers.split(",")) if a.layers else None
 tot = {}
