@@ -99,6 +99,27 @@ int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* 
                     (long)M, C, (float*)scratch, S_(stream));
 }
 
+int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
+                              const void* addend, void* dx, const void* bn_y, const void* bn_mask, const float* bn_coef,
+                              float* rows, int* nrows, void* stream) {
+  if (!bn_y || !bn_coef || !rows || !nrows) ECG_FAIL(ECGMM_ERR_SHAPE, "conv_bwd_data_bnred: null BatchNorm operand");
+  const ConvGeom g = geom_of(c);
+  *nrows = 0;
+  if (!ecg_conv_halo_ok(dtype, 1, g))
+    return ecg_conv_igemm(dtype, 1, g, dy, w_dgrad, dx, nullptr, addend, nullptr, 0, S_(stream));
+  ConvEpi e = {};
+  e.wg_rows = 1; e.red_y = bn_y; e.red_mask = bn_mask; e.red_coef = bn_coef; e.red_rows = rows;
+  int rc = ecg_conv_igemm(dtype, 1, g, dy, w_dgrad, dx, nullptr, addend, nullptr, 0, S_(stream), &e);
+  if (rc == 0 && e.red_done) *nrows = e.red_rows_n;
+  return rc;
+}
+int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
+                           const float* gamma, float* dgamma, float* dbeta, void* dy, const float* rows, int nrows,
+                           int64_t M, int C, void* scratch, void* stream) {
+  return ecg_bn_bwd_tail(dtype, dout, maskref, y, coef, gamma, dgamma, dbeta, dy, rows, nrows, (long)M, C,
+                         (float*)scratch, S_(stream));
+}
+
 int ecgmm_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int N, int H, int W,
                          int C, void* stream) {
   return ecg_bnrelu_maxpool(dtype, y, coef, out, idx, N, H, W, C, S_(stream));

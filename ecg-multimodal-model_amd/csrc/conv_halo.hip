@@ -38,13 +38,23 @@ struct HaloParams {
   void* dst;
   const float* bias;
   const void* addend;
-  float* stats;
+  float* stats;          // forward: BatchNorm partial sums (sum y, sum y^2) or null
+  // dgrad: reduction pass of the BatchNorm backward that consumes this gradient, fused into the epilogue (or null):
+  //   g = [mask] * dst (as stored, bf16);  rows of (sum g, sum g * (y - mean))
+  //   red_mask == red_y: the ReLU input was bn(y) itself, mask = (y * scale + shift > 0), dst is stored unmasked;
+  //   otherwise mask = (red_mask > 0) and dst is stored MASKED (the residual-branch gradient the apply pass reads)
+  const void* red_y;
+  const void* red_mask;
+  const float* red_coef;  // forward coefficients [4][Cd]: scale, shift, mean, invstd
+  float* red_rows;
+  int wg_rows;            // 1: ONE partial row per workgroup (accumulated over its tiles in LDS, written at the end);
+                          // 0: one row per 64 pixels, the layout conv_igemm writes (forward statistics only)
   int M, H, W, Cs, Cd, ph, pw, act;
   int ncs;    // Cs / 64
   int HL;     // ph * W + pw: halo pixels on each side
   int hrows;  // 256 + 2 * HL
   int ntm;    // pixel tiles (M / 256)
-  int ntiles; // ntm * (Cd / BN)
+  int ntn;    // channel tiles (Cd / BN); gridDim.x is a multiple of it
 };
 
 __device__ __forceinline__ void hdma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_wave_base, unsigned voffset,
@@ -83,7 +93,10 @@ template <int BN> struct HaloCfg {
   static constexpr int WSTAGE = BN * 128;
   static constexpr int NWS = 4;
   static constexpr int WBASE = 2 * HBUF;
-  static constexpr int LDS = WBASE + NWS * WSTAGE;
+  static constexpr int SBASE = WBASE + NWS * WSTAGE;   // fp32 [4 pixel quarters][2][BN] partial-row accumulators
+  static constexpr int CBASE = SBASE + 4 * 2 * BN * 4;   // fp32 [3][BN]: scale, shift, mean of the fused BatchNorm backward
+  static constexpr int TRASH = CBASE + 3 * BN * 4;       // 256 B nobody reads: destination of the L2-prefetch DMAs
+  static constexpr int LDS = TRASH + 256;
   static constexpr int WPS = BN / 64;                 // weight DMA pieces per wave per step
   static constexpr int NPW_MAX = HCAP / 64;           // halo DMA pieces per wave per channel slice
 };
@@ -102,14 +115,12 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   const int wp = wv & 3, wc = wv >> 2;
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x;
-  // Workgroups are PERSISTENT: workgroup b takes tiles perm(b), perm(b) + G, ... of the (channel tile, pixel tile) list.
-  // perm gives the workgroups that share an XCD (equal b % 8: MI355X_MICROARCH.md, dispatch) a contiguous run of pixel
-  // tiles, whose halos overlap, so they share that XCD's L2 -- speed only, bijective for any G.
-  int T;
-  {
-    const int q = G >> 3, r = G & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
+  // Workgroups are PERSISTENT, and a workgroup stays on ONE channel tile: workgroup b owns channel tile b % ntn and the
+  // pixel tiles b / ntn, b / ntn + G / ntn, ... (G is a multiple of ntn).  Equal b % 8 = same XCD (MI355X_MICROARCH.md,
+  // dispatch) and ntn divides 8, so an XCD's L2 holds one channel tile's weights -- speed only.  One channel tile per
+  // workgroup is what lets the per-channel partial sums accumulate over all of its tiles.
+  const int nt = (int)blockIdx.x % p.ntn, kq = (int)blockIdx.x / p.ntn, Gk = G / p.ntn;
+  const int n0 = nt * BN;
   const unsigned pixb = (unsigned)p.Cs * 2u;  // bytes per pixel row of the source
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((size_t)p.M * pixb), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
@@ -229,23 +240,47 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   // ---- tile loop.  Per tile: the fills of its first halo slice and first two weight slots are ALREADY in flight
   // (issued before the loop for the first tile, and right after the previous tile's last K step otherwise: they land
   // while that tile's epilogue runs), the address table is built, then one wait + barrier, then the K loop.
-  int nt = T / p.ntm, mt = T - nt * p.ntm;
-  int m0 = mt * HBM_, n0 = nt * BN;
+  int mt = kq;
+  int m0 = mt * HBM_;
   unsigned wrow[C::WPS];
+  set_wrow(wrow, n0);
   int g0 = 0;  // K steps done so far (all tiles): step g uses weight slot g & 3
   int qs = 0;  // channel slices done so far: slice q uses halo buffer q & 1
-  auto tile_fills = [&](int m0_, int n0_) {
+  auto tile_fills = [&](int m0_) {
     set_hoff(m0_);
-    set_wrow(wrow, n0_);
     dma_halo((unsigned)(qs & 1) * C::HBUF, 0, 0, C::NPW_MAX);
     dma_w(wrow, g0 & 3, 0, 0);
     dma_w(wrow, (g0 + 1) & 3, 0, 1);
     dma_w(wrow, (g0 + 2) & 3, 0, 2);
   };
   if (tid < 16) *reinterpret_cast<u32x4*>(smem + (tid >> 3) * C::HBUF + C::HCAP * 128 + (tid & 7) * 16) = (u32x4){0u, 0u, 0u, 0u};
-  tile_fills(m0, n0);
+  float* const sacc = reinterpret_cast<float*>(smem + C::SBASE);
+  for (int i = tid; i < 4 * 2 * BN; i += HTHREADS) sacc[i] = 0.f;
+  float* const scoef = reinterpret_cast<float*>(smem + C::CBASE);
+  if (MODE == 1 && p.red_y)
+    for (int i = tid; i < 3 * BN; i += HTHREADS) scoef[i] = p.red_coef[(i / BN) * p.Cd + n0 + (i % BN)];
+  tile_fills(m0);
 
   u32x4 fa0[TC], fb0[TP], fa1[TC], fb1[TP];
+
+  // The epilogue's operand tensors (residual addend, fused BatchNorm-backward y and mask) are read once per tile, right
+  // when the tile ends: their HBM latency would be exposed once per tile.  At the start of the tile's last K slice every
+  // wave touches the 64 lines it will need (its 64 pixels x its channel range = one 128-byte line each) with ONE 4-byte
+  // LDS-DMA per tensor into a trash area: no registers, and the lines wait in L2.  Always three DMAs (an absent tensor
+  // is replaced by one line of the weights), so the counted waits of the slice stay compile-time constants.
+  const bf16_t* const pf_base[3] = {(const bf16_t*)p.addend, MODE == 1 ? (const bf16_t*)p.red_y : nullptr,
+                                    MODE == 1 && p.red_mask != p.red_y ? (const bf16_t*)p.red_mask : nullptr};
+  auto prefetch_epilogue_operands = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const size_t e = (size_t)(m0 + wp * 64 + lane) * p.Cd + n0 + wc * (BN / 2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bf16_t* g = pf_base[k] ? pf_base[k] + e : (const bf16_t*)p.wpk;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(smem + C::TRASH), 4, 0, 0);
+    }
+#endif
+  };
 
   // One channel slice = RS steps, fully unrolled and branch-free, so that every wait count is a compile-time constant
   // and hipcc's LDS-read bookkeeping stays exact.  LAST = the tile's last slice: no fills past the tile's end.
@@ -269,8 +304,11 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       // barrier), the next slice's halo into the other halo buffer.  Two steps' fills stay in flight across each barrier.
       const auto n_halo = [](int tt, bool last) { return (!last && tt < RS - 1 && tt * HPS < C::NPW_MAX)
                                                       ? ((tt + 1) * HPS < C::NPW_MAX ? HPS : C::NPW_MAX - tt * HPS) : 0; };
-      const auto n_fill = [&](int tt, bool last) { return ((last && tt + 3 >= RS) ? 0 : C::WPS) + n_halo(tt, last); };
+      const auto n_fill = [&](int tt, bool last) {
+        return ((last && tt + 3 >= RS) ? 0 : C::WPS) + n_halo(tt, last) + ((last && tt == 0) ? 3 : 0);
+      };
       const bool wrap = t + 3 >= RS;
+      if (LAST && t == 0) prefetch_epilogue_operands();   // 3 DMAs, counted in n_fill
 #if !(defined(HALO_ABL) && HALO_ABL == 3)   // diagnostic 3: no fills inside the K loop
       if (!(LAST && wrap)) dma_w(wrow, (s + 3) & 3, cs + (wrap ? 1 : 0), (t + 3) % RS);
       if (n_halo(t, LAST) > 0) dma_halo(hbn, cs + 1, t * HPS, (t + 1) * HPS);
@@ -329,7 +367,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
     // only make the wait stricter.
     constexpr int N_DATA = TC * TP / 2, N_STAT = 2 * TC;
     if (first_tile) wait_vmcnt<0>();
-    else if (p.stats) wait_vmcnt<N_DATA + N_STAT>();
+    else if (MODE == 0 && p.stats && !p.wg_rows) wait_vmcnt<N_DATA + N_STAT>();
     else wait_vmcnt<N_DATA>();
     first_tile = false;
     wait_lds();
@@ -342,90 +380,231 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
     }
     for (int cs = 0; cs + 1 < p.ncs; ++cs) slice(cs, std::integral_constant<bool, false>{});
     slice(p.ncs - 1, std::integral_constant<bool, true>{});
-    // every wave is past the last step's barrier, i.e. has read its last fragments: the halo buffer and the two weight
-    // slots the next tile starts with are free -- start its fills now, under this tile's epilogue
-    const int Tn = T + G;
-    const bool more = Tn < p.ntiles;
+    // every wave is past the last step's barrier, i.e. has read its last fragments: the halo buffer and the weight
+    // slots the next tile starts with are free; its fills are issued from inside this tile's epilogue (below)
+    // the K loop ends HERE for every accumulator (hipcc otherwise sinks the last slice's MFMAs of the second pixel half
+    // below the epilogue's first phase and keeps their fragments in scratch), and nothing of the epilogue -- its operand
+    // loads! -- is scheduled up into the K loop
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) asm volatile("" : "+v"(acc[a][b]));
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = mt + Gk < p.ntm;
     const int mt_cur = mt, m0_cur = m0, n0_cur = n0;
     if (more) {
-      nt = Tn / p.ntm;
-      mt = Tn - nt * p.ntm;
+      mt += Gk;
       m0 = mt * HBM_;
-      n0 = nt * BN;
-      T = Tn;
-      tile_fills(m0, n0);
     }
 
 #if !(defined(HALO_ABL) && HALO_ABL == 4)   // diagnostic 4: no epilogue (accumulators kept alive)
     // ---- epilogue of this tile (whole tiles only: the host dispatches this kernel for M % 256 == 0, Cd % BN == 0).
-    // lane owns pixel fr x 4 consecutive channels fq*4.. of each 16 x 16 tile; the 8-byte packs of two neighbouring
-    // channel tiles are exchanged between lane rows (v_permlane16_swap) so every lane stores 16 contiguous bytes
+    // A lane owns pixel fr x 4 consecutive channels (fq*4..) of each 16 x 16 tile; the 8-byte bf16 packs of two
+    // neighbouring channel tiles are exchanged between lane rows (v_permlane16_swap), so that a lane ends up with 8
+    // consecutive channels of one pixel: 16-byte stores -- and 16-byte loads of the fused BatchNorm-backward operands.
+    //
+    // vmcnt retires vector-memory operations IN ORDER, loads and stores alike: a load issued behind a store (or behind
+    // the next tile's fills) cannot be waited for without waiting for that store's write acknowledgement (or for the
+    // fills to land).  So the epilogue runs in phases over the two pixel halves h of the wave's 64 pixels:
+    //     loads(0) -> compute(0) -> loads(1) -> next tile's fills -> stores(0) -> compute(1) -> stores(1)
+    // every wait for loads(h) leaves only younger operations in flight, and the wait that opens the next tile ("fills
+    // landed") leaves exactly the N_DATA stores.  The operand lines were pulled into L2 during the last K slice (below).
     {
+      constexpr int TA = TC / 2;   // channel-tile pairs
+      const bf16_t* __restrict__ red_y = MODE == 1 ? (const bf16_t*)p.red_y : nullptr;
+      const bf16_t* __restrict__ red_m = MODE == 1 ? (const bf16_t*)p.red_mask : nullptr;
+      const bool red = red_y != nullptr, red_sep = red && red_m != red_y;
+      const int cw = n0_cur + wc * (BN / 2);                                     // first channel of this wave
+      const int cl = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;                      // + 32 * pair: first of the lane's 8 stored channels
       size_t prow[TP];
 #pragma unroll
-      for (int b = 0; b < TP; ++b) prow[b] = (size_t)(m0_cur + wp * 64 + b * 16 + fr) * p.Cd + n0_cur + wc * (BN / 2);
-      float s1[TC][4], s2[TC][4];
+      for (int b = 0; b < TP; ++b) prow[b] = (size_t)(m0_cur + wp * 64 + b * 16 + fr) * p.Cd + cw;
+      float s1[TC][4], s2[TC][4];          // forward statistics: fp32 values, lane's 4 + 4 channels of a tile pair
+      float q1[TA][8], q2[TA][8];          // backward reduction: stored values, lane's 8 stored channels of a pair
       f32x4 bias4[TC];
 #pragma unroll
       for (int a = 0; a < TC; ++a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) s1[a][j] = s2[a][j] = 0.f;
-        bias4[a] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0_cur + wc * (BN / 2) + a * 16 + fq * 4)
-                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bias4[a] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cw + a * 16 + fq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-      for (int a = 0; a < TC; a += 2)
+      for (int ap = 0; ap < TA; ++ap)
 #pragma unroll
-        for (int b = 0; b < TP; ++b) {
-          f32x4 v0 = acc[a][b], v1 = acc[a + 1][b];
-          if (p.bias) {
-            v0 += bias4[a];
-            v1 += bias4[a + 1];
-          }
+        for (int j = 0; j < 8; ++j) q1[ap][j] = q2[ap][j] = 0.f;
+      auto unpk = [](unsigned lo, unsigned hi) -> f32x4 {
+        return (f32x4){__uint_as_float(lo << 16), __uint_as_float(lo & 0xFFFF0000u), __uint_as_float(hi << 16),
+                       __uint_as_float(hi & 0xFFFF0000u)};
+      };
+      uint2 adv[2][TC][2];       // [half][channel tile][pixel tile of the half]: residual addend, pre-swap layout
+      u32x4 yq[2][TA][2], mq[2][TA][2], oq[2][TA][2];
+      auto loads = [&](auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int b = h * 2 + bb;
           if (addend) {
-            const bf16_t* ap = addend + prow[b] + fq * 4;
-            const uint2 p0 = *reinterpret_cast<const uint2*>(ap + a * 16), p1 = *reinterpret_cast<const uint2*>(ap + (a + 1) * 16);
-            v0 += (f32x4){__uint_as_float(p0.x << 16), __uint_as_float(p0.x & 0xFFFF0000u), __uint_as_float(p0.y << 16),
-                          __uint_as_float(p0.y & 0xFFFF0000u)};
-            v1 += (f32x4){__uint_as_float(p1.x << 16), __uint_as_float(p1.x & 0xFFFF0000u), __uint_as_float(p1.y << 16),
-                          __uint_as_float(p1.y & 0xFFFF0000u)};
-          }
-          if (p.act == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              v0[j] = fmaxf(v0[j], 0.f);
-              v1[j] = fmaxf(v1[j], 0.f);
+            for (int a = 0; a < TC; ++a) adv[h][a][bb] = *reinterpret_cast<const uint2*>(addend + prow[b] + a * 16 + fq * 4);
+          }
+          if (MODE == 1 && red) {
+#pragma unroll
+            for (int ap = 0; ap < TA; ++ap) {
+              yq[h][ap][bb] = *reinterpret_cast<const u32x4*>(red_y + prow[b] + ap * 32 + cl);
+              if (red_sep) mq[h][ap][bb] = *reinterpret_cast<const u32x4*>(red_m + prow[b] + ap * 32 + cl);
             }
           }
+        }
+      };
+      auto compute = [&](auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            s1[a][j] += v0[j];
-            s2[a][j] += v0[j] * v0[j];
-            s1[a + 1][j] += v1[j];
-            s2[a + 1][j] += v1[j] * v1[j];
+        for (int ap = 0; ap < TA; ++ap) {
+          const int a = 2 * ap;
+          f32x4 c_sc[2], c_sh[2], c_mu[2];
+          if (MODE == 1 && red) {   // coefficients of the lane's 8 stored channels (staged in LDS at kernel start)
+            const float* cf = scoef + wc * (BN / 2) + ap * 32 + cl;
+            c_sc[0] = *reinterpret_cast<const f32x4*>(cf); c_sc[1] = *reinterpret_cast<const f32x4*>(cf + 4);
+            c_sh[0] = *reinterpret_cast<const f32x4*>(cf + BN); c_sh[1] = *reinterpret_cast<const f32x4*>(cf + BN + 4);
+            c_mu[0] = *reinterpret_cast<const f32x4*>(cf + 2 * BN); c_mu[1] = *reinterpret_cast<const f32x4*>(cf + 2 * BN + 4);
           }
-          const unsigned x0 = pack_bf16x2(v0[0], v0[1]), y0 = pack_bf16x2(v0[2], v0[3]);
-          const unsigned x1 = pack_bf16x2(v1[0], v1[1]), y1 = pack_bf16x2(v1[2], v1[3]);
-          auto lo = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
-          auto hi = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
-          const int ch = (fq & 1) ? (a + 1) * 16 + (fq - 1) * 4 : a * 16 + fq * 4;
-          *reinterpret_cast<u32x4*>(dst + prow[b] + ch) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const int b = h * 2 + bb;
+            f32x4 v0 = acc[a][b], v1 = acc[a + 1][b];
+            if (p.bias) {
+              v0 += bias4[a];
+              v1 += bias4[a + 1];
+            }
+            if (addend) {
+              v0 += unpk(adv[h][a][bb].x, adv[h][a][bb].y);
+              v1 += unpk(adv[h][a + 1][bb].x, adv[h][a + 1][bb].y);
+            }
+            if (p.act == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                v0[j] = fmaxf(v0[j], 0.f);
+                v1[j] = fmaxf(v1[j], 0.f);
+              }
+            }
+            if (MODE == 0) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                s1[a][j] += v0[j];
+                s2[a][j] += v0[j] * v0[j];
+                s1[a + 1][j] += v1[j];
+                s2[a + 1][j] += v1[j] * v1[j];
+              }
+            }
+            const unsigned x0 = pack_bf16x2(v0[0], v0[1]), y0 = pack_bf16x2(v0[2], v0[3]);
+            const unsigned x1 = pack_bf16x2(v1[0], v1[1]), y1 = pack_bf16x2(v1[2], v1[3]);
+            auto lo = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+            auto hi = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
+            u32x4 o = (u32x4){lo[0], hi[0], lo[1], hi[1]};    // 8 consecutive channels (cl + 32 * ap ..) of pixel b
+            if (MODE == 1 && red) {
+              // the BatchNorm backward that consumes this gradient sums what is STORED (bf16), masked by its ReLU
+              const f32x4 d[2] = {unpk(o[0], o[1]), unpk(o[2], o[3])};
+              const u32x4 yr = yq[h][ap][bb];
+              const f32x4 yv[2] = {unpk(yr[0], yr[1]), unpk(yr[2], yr[3])};
+              f32x4 g[2];
+              if (red_sep) {
+                const u32x4 mr = mq[h][ap][bb];
+                const f32x4 mv[2] = {unpk(mr[0], mr[1]), unpk(mr[2], mr[3])};
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) g[u][j] = mv[u][j] > 0.f ? d[u][j] : 0.f;
+                o = (u32x4){pack_bf16x2(g[0][0], g[0][1]), pack_bf16x2(g[0][2], g[0][3]), pack_bf16x2(g[1][0], g[1][1]),
+                            pack_bf16x2(g[1][2], g[1][3])};   // exact: the kept values are bf16 already
+              } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) g[u][j] = (yv[u][j] * c_sc[u][j] + c_sh[u][j]) > 0.f ? d[u][j] : 0.f;
+              }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  q1[ap][u * 4 + j] += g[u][j];
+                  q2[ap][u * 4 + j] += g[u][j] * (yv[u][j] - c_mu[u][j]);
+                }
+            }
+            oq[h][ap][bb] = o;
+          }
         }
 #endif
-      if (p.stats) {  // BatchNorm partial sums: one row per 64 pixels (the rows conv_igemm writes: 2 per 128 pixels)
-        float* srow = p.stats + (size_t)(mt_cur * 4 + wp) * 2 * p.Cd + n0_cur + wc * (BN / 2) + fq * 4;
+      };
+      auto stores = [&](auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
 #pragma unroll
-        for (int a = 0; a < TC; ++a) {
-          f32x4 r1, r2;
+        for (int ap = 0; ap < TA; ++ap)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            r1[j] = row16_sum(s1[a][j]);
-            r2[j] = row16_sum(s2[a][j]);
+          for (int bb = 0; bb < 2; ++bb) *reinterpret_cast<u32x4*>(dst + prow[h * 2 + bb] + ap * 32 + cl) = oq[h][ap][bb];
+      };
+      using H0 = std::integral_constant<int, 0>;
+      using H1 = std::integral_constant<int, 1>;
+      if (addend == nullptr && !red) {
+        // nothing to load: fills first (they have the whole epilogue to land), stores as soon as a half is computed
+        if (more) tile_fills(m0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(H0{});
+        stores(H0{});
+        compute(H1{});
+        stores(H1{});
+      } else {
+        loads(H0{});
+        compute(H0{});
+        loads(H1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) tile_fills(m0);
+        __builtin_amdgcn_sched_barrier(0);
+        stores(H0{});
+        compute(H1{});
+        stores(H1{});
+      }
+      if ((MODE == 0 && p.stats) || (MODE == 1 && red)) {
+        // per-channel partial sums of this wave's 64 pixels: 16-lane DPP reduction, then either a row of the per-64-pixel
+        // layout (what conv_igemm writes: forward only), or -- wg_rows -- added to this wave's LDS accumulators (only this
+        // wave's fr == 0 lanes touch its [pixel quarter][channel] slots: plain read-modify-write, fixed order, reproducible)
+        float* lrow = sacc + wp * 2 * BN + wc * (BN / 2);
+        if (MODE == 0) {
+          float* srow = p.stats + (size_t)(mt_cur * 4 + wp) * 2 * p.Cd + cw + fq * 4;
+#pragma unroll
+          for (int a = 0; a < TC; ++a) {
+            f32x4 r1, r2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              r1[j] = row16_sum(s1[a][j]);
+              r2[j] = row16_sum(s2[a][j]);
+            }
+            if (fr == 0) {
+              if (p.wg_rows) {
+                *reinterpret_cast<f32x4*>(lrow + a * 16 + fq * 4) += r1;
+                *reinterpret_cast<f32x4*>(lrow + BN + a * 16 + fq * 4) += r2;
+              } else {
+                *reinterpret_cast<f32x4*>(srow + a * 16) = r1;
+                *reinterpret_cast<f32x4*>(srow + p.Cd + a * 16) = r2;
+              }
+            }
           }
-          if (fr == 0) {
-            *reinterpret_cast<f32x4*>(srow + a * 16) = r1;
-            *reinterpret_cast<f32x4*>(srow + p.Cd + a * 16) = r2;
+        } else {
+#pragma unroll
+          for (int ap = 0; ap < TA; ++ap) {
+            f32x4 r1[2], r2[2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              r1[j >> 2][j & 3] = row16_sum(q1[ap][j]);
+              r2[j >> 2][j & 3] = row16_sum(q2[ap][j]);
+            }
+            if (fr == 0) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                *reinterpret_cast<f32x4*>(lrow + ap * 32 + cl + u * 4) += r1[u];
+                *reinterpret_cast<f32x4*>(lrow + BN + ap * 32 + cl + u * 4) += r2[u];
+              }
+            }
           }
         }
       }
@@ -438,10 +617,20 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
 #endif
     if (!more) break;
   }
+  if (p.wg_rows && (p.stats || p.red_y)) {
+    // one partial row per workgroup: the four pixel quarters' accumulators, summed in fixed order
+    __syncthreads();
+    float* rows = p.red_y ? p.red_rows : p.stats;
+    for (int i = tid; i < 2 * BN; i += HTHREADS) {
+      const int which = i / BN, c = i - which * BN;
+      const float v = ((sacc[0 * 2 * BN + i] + sacc[1 * 2 * BN + i]) + sacc[2 * 2 * BN + i]) + sacc[3 * 2 * BN + i];
+      rows[((size_t)kq * 2 + which) * p.Cd + n0 + c] = v;
+    }
+  }
 }
 
 template <int BN, int RS, int MODE>
-int launch_halo(const HaloParams& p, hipStream_t stream) {
+int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   using C = HaloCfg<BN>;
   static bool attr_set[16] = {false};
   int dev = 0;
@@ -459,10 +648,14 @@ int launch_halo(const HaloParams& p, hipStream_t stream) {
   }
   HaloParams q = p;
   q.ntm = p.M / HBM_;
-  q.ntiles = q.ntm * (p.Cd / BN);
+  q.ntn = p.Cd / BN;
   const int cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
-  dim3 grid(q.ntiles < cus ? q.ntiles : cus);   // persistent: one workgroup per CU walks the tile list
-  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE>), grid, dim3(HTHREADS), C::LDS, stream, q);
+  // persistent: one workgroup per CU; Gk workgroups per channel tile (each walks pixel tiles k, k + Gk, ...)
+  int Gk = cus / q.ntn;
+  if (Gk > q.ntm) Gk = q.ntm;
+  if (Gk < 1) Gk = 1;
+  *rows_out = Gk;
+  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE>), dim3(Gk * q.ntn), dim3(HTHREADS), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
   return 0;
 }
@@ -500,8 +693,26 @@ bool ecg_conv_halo_ok(int dtype, int mode, const ConvGeom& g) {
   return g.R == 3 || Cs >= 256;
 }
 
+// partial rows a halo launch with ConvEpi.wg_rows writes: one per workgroup of a channel tile
+int ecg_conv_halo_rows(int mode, const ConvGeom& g) {
+  const int Cd = mode == 0 ? g.Cout : g.Cin;
+  const int ntn = Cd > 64 ? Cd / 128 : 1, ntm = g.N * g.H * g.W / HBM_;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  static int ncu_cache[16] = {0};
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16) {
+    if (ncu_cache[dev] == 0)
+      ncu_cache[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus = ncu_cache[dev];
+  }
+  int Gk = cus / ntn;
+  if (Gk > ntm) Gk = ntm;
+  return Gk < 1 ? 1 : Gk;
+}
+
 int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst, const float* bias,
-                  const void* addend, float* stats, int act, hipStream_t stream) {
+                  const void* addend, float* stats, int act, ConvEpi* epi, hipStream_t stream) {
   HaloParams p;
   memset(&p, 0, sizeof(p));
   p.src = src; p.wpk = wpk; p.dst = dst; p.bias = bias; p.addend = addend; p.stats = stats; p.act = act;
@@ -511,11 +722,29 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
   p.ncs = p.Cs / 64;
   p.HL = g.pad_h * g.W + g.pad_w;
   p.hrows = 256 + 2 * p.HL;
-  const bool wide = p.Cd > 64;
-  if (g.R == 3) {
-    if (mode == 0) return wide ? launch_halo<128, 9, 0>(p, stream) : launch_halo<64, 9, 0>(p, stream);
-    return wide ? launch_halo<128, 9, 1>(p, stream) : launch_halo<64, 9, 1>(p, stream);
+  if (epi) {
+    p.wg_rows = epi->wg_rows;
+    if (epi->red_y) {
+      if (stats || !epi->red_coef || !epi->red_rows || !epi->wg_rows)
+        ECG_FAIL(ECGMM_ERR_SHAPE, "conv_halo: fused BatchNorm-backward reduction needs coefficients, rows, wg_rows and no forward statistics");
+      p.red_y = epi->red_y; p.red_mask = epi->red_mask ? epi->red_mask : epi->red_y; p.red_coef = epi->red_coef;
+      p.red_rows = epi->red_rows;
+    }
   }
-  if (mode == 0) return wide ? launch_halo<128, 3, 0>(p, stream) : launch_halo<64, 3, 0>(p, stream);
-  return wide ? launch_halo<128, 3, 1>(p, stream) : launch_halo<64, 3, 1>(p, stream);
+  int wg = 0;
+  const bool wide = p.Cd > 64;
+  int rc;
+  if (g.R == 3) {
+    if (mode == 0) rc = wide ? launch_halo<128, 9, 0>(p, &wg, stream) : launch_halo<64, 9, 0>(p, &wg, stream);
+    else rc = wide ? launch_halo<128, 9, 1>(p, &wg, stream) : launch_halo<64, 9, 1>(p, &wg, stream);
+  } else {
+    if (mode == 0) rc = wide ? launch_halo<128, 3, 0>(p, &wg, stream) : launch_halo<64, 3, 0>(p, &wg, stream);
+    else rc = wide ? launch_halo<128, 3, 1>(p, &wg, stream) : launch_halo<64, 3, 1>(p, &wg, stream);
+  }
+  if (epi) {
+    epi->stats_rows = p.wg_rows ? wg : 2 * ceil_div(p.M, 128);
+    epi->red_done = p.red_y != nullptr;
+    epi->red_rows_n = p.red_y ? wg : 0;
+  }
+  return rc;
 }

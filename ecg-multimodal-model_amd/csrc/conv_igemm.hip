@@ -561,7 +561,7 @@ static inline double conv_flops(const ConvGeom& g) {
 
 // mode 0: forward (src = x, dst = y); mode 1: dgrad (src = dy, dst = dx; g still describes the FORWARD conv)
 int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst,
-                   const float* bias, const void* addend, float* stats, int act, hipStream_t stream) {
+                   const float* bias, const void* addend, float* stats, int act, hipStream_t stream, ConvEpi* epi) {
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.src = src; p.wpk = wpk; p.dst = dst; p.bias = bias; p.addend = addend; p.stats = stats; p.act = act;
@@ -586,10 +586,16 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
                    conv_flops(g), bytes, stream);
   }
   int rc;
-  if (ecg_conv_halo_ok(dtype, mode, g))  // stride-1 3x3 / 1x3 on whole 256-pixel tiles: halo-resident kernel (conv_halo.hip)
-    rc = ecg_conv_halo(mode, g, src, wpk, dst, bias, addend, stats, act, stream);
-  else
+  if (ecg_conv_halo_ok(dtype, mode, g)) {  // stride-1 3x3 / 1x3 on whole 256-pixel tiles: halo-resident kernel (conv_halo.hip)
+    rc = ecg_conv_halo(mode, g, src, wpk, dst, bias, addend, stats, act, epi, stream);
+  } else {
+    if (epi) {
+      epi->stats_rows = ecg_conv_stats_rows(M);
+      epi->red_done = 0;
+      epi->red_rows_n = 0;
+    }
     rc = dtype == ECGMM_BF16 ? launch_T<bf16_t>(p, mode, stream) : launch_T<float>(p, mode, stream);
+  }
   ecg_prof_end(stream);
   return rc;
 }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                                double count, const float* __restrict__ gamma,
                                                                const float* __restrict__ coef, float* dgamma,
-                                                               float* dbeta, float* __restrict__ bcoef) {
+                                                               float* dbeta, float* __restrict__ bcoef, int centered) {
   __shared__ double sh[2][16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
@@ -337,6 +337,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
       s1 += sh[0][k][threadIdx.x];
       s2 += sh[1][k][threadIdx.x];
     }
+    // centered: the rows hold sum g * (y - mean) (reduction fused into a conv epilogue), not sum g * xhat
+    if (centered) s2 *= (double)coef[3 * C + c];
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     bcoef[c] = (gamma ? gamma[c] : 1.f) * coef[3 * C + c];
@@ -842,7 +844,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
     const float* pr = partial;
     int rows = grid;  // <= 256: folded by the finalize kernel itself (16 slices x 16 rows)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, pr, rows, C, (double)M,
-                       gamma, coef, dgamma, dbeta, bcoef);
+                       gamma, coef, dgamma, dbeta, bcoef, 0);
   }
   ECG_CHECK_LAUNCH("bn_bwd_finalize");
   if (!dy) return 0;
@@ -855,6 +857,28 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
     hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, grid, C, dbias, 0);
     ECG_CHECK_LAUNCH("rows_sum");
   }
+  return 0;
+}
+
+// finalize + apply of a BatchNorm backward whose reduction rows already exist: `partial` = [rows <= 256][2][C] of
+// (sum g, sum g * (y - mean)) written by the epilogue of the dgrad that produced `dout` (conv_halo.hip, ConvEpi).
+// maskref as in ecg_bn_bwd (null when `dout` was stored already masked).
+int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
+                    const float* gamma, float* dgamma, float* dbeta, void* dy, const float* partial, int rows, long M,
+                    int C, float* scratch, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
+  if (rows < 1 || rows > 256) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd_tail: %d partial rows (1..256)", rows);
+  const int grid = bn_bwd_rows(dtype, M, C);
+  float* bcoef = scratch + (size_t)(grid + ECG_TAIL_ROWS) * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, (double)M,
+                     gamma, coef, dgamma, dbeta, bcoef, 1);
+  ECG_CHECK_LAUNCH("bn_bwd_finalize");
+  BnBwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.dout = dout; p.maskref = maskref; p.y = y; p.coef = coef; p.M = M; p.C = C; p.rows_per_sample = 1;
+  p.bcoef = bcoef; p.dy = dy;
+  DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
+  ECG_CHECK_LAUNCH("bn_bwd_apply");
   return 0;
 }
 

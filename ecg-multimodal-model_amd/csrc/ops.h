@@ -4,12 +4,28 @@
 
 // conv_igemm.hip
 int ecg_conv_stats_rows(long M);
+// Optional epilogue extras of a convolution launch (the encoder plans use them; the C ABI passes none).
+struct ConvEpi {
+  // in -- dgrad only: fuse the REDUCTION pass of the BatchNorm backward that consumes this gradient into the epilogue
+  // (done by the halo kernel only: check red_done).  g = [mask] * dst as stored; rows of (sum g, sum g * (y - mean)).
+  const void* red_y;      // raw conv output that BatchNorm normalised (same [pixels][channels] layout as dst), or null
+  const void* red_mask;   // null / == red_y: mask = (bn(y) > 0), dst stored unmasked; else mask = (red_mask > 0), dst stored MASKED
+  const float* red_coef;  // that BatchNorm's forward coefficients [4][C]
+  float* red_rows;        // [>= 256 rows][2][C]
+  int wg_rows;            // in: 1 = the launch may write ONE partial row per workgroup instead of one per 64 pixels
+  // out
+  int stats_rows;         // rows of `stats` the forward launch wrote
+  int red_done;           // 1 = red_rows holds red_rows_n rows; 0 = the caller runs the separate reduction pass
+  int red_rows_n;
+};
 int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst,
-                   const float* bias, const void* addend, float* stats, int act, hipStream_t stream);
+                   const float* bias, const void* addend, float* stats, int act, hipStream_t stream,
+                   ConvEpi* epi = nullptr);
 // conv_halo.hip: stride-1 "same" 3x3 / 1x3 convolutions with a halo-resident activation tile (bf16, whole 256-pixel tiles)
 bool ecg_conv_halo_ok(int dtype, int mode, const ConvGeom& g);
+int ecg_conv_halo_rows(int mode, const ConvGeom& g);
 int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst, const float* bias,
-                  const void* addend, float* stats, int act, hipStream_t stream);
+                  const void* addend, float* stats, int act, ConvEpi* epi, hipStream_t stream);
 // conv_wgrad.hip
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g);
 int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, float* grad_oihw, int accumulate,
@@ -36,6 +52,9 @@ size_t ecg_bn_bwd_scratch(int dtype, long M, int C);
 int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
                int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma, float* dbeta,
                void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream);
+int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
+                    const float* gamma, float* dgamma, float* dbeta, void* dy, const float* partial, int rows, long M,
+                    int C, float* scratch, hipStream_t stream);
 int ecg_rows_sum(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t stream);
 int ecg_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, unsigned char* idx, int N, int H, int W,
                        int C, hipStream_t stream);

@@ -146,6 +146,7 @@ struct BwdWs {
   void* big1;   // stem: dy0
   float* dpooled;
   float* bn_scratch;
+  float *red1, *red2;  // partial rows of BatchNorm-backward reductions fused into dgrad epilogues (ConvEpi): bn1 / bn2
   void* wg_ws; size_t wg_bytes;
   void* stem_ws; size_t stem_bytes;  // the stem's slab buffer (it runs on the caller's stream, concurrently with side-stream wgrads)
   void* lin_ws; size_t lin_bytes;
@@ -185,6 +186,8 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
     }
   }
   w.bn_scratch = (float*)a.take_bytes(bn);
+  w.red1 = a.take<float>((size_t)256 * 2 * 512);
+  w.red2 = a.take<float>((size_t)256 * 2 * 512);
   w.wg_ws = a.take_bytes(wg);
   w.wg_bytes = wg;
   w.stem_bytes = ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);
@@ -300,11 +303,14 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
     const int rows = ecg_conv_stats_rows(M);
     ConvGeom g1 = make_geom(N, k.hin, k.win, k.cin, k.cout, 3, 3, k.stride, 1, 1);
     ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
-    ECG_TRY(ecg_conv_igemm(dt, 0, g1, cur, b.w1f, b.y1, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
-    ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_bn1, buffers, k.b_bn1, b.coef1, s));
+    // (ConvEpi.wg_rows: the halo kernel writes one partial-sum row per workgroup instead of one per 64 pixels)
+    ConvEpi e1 = {}, e2 = {};
+    e1.wg_rows = e2.wg_rows = 1;
+    ECG_TRY(ecg_conv_igemm(dt, 0, g1, cur, b.w1f, b.y1, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s, &e1));
+    ECG_TRY(bn_coef(r, w.stats, e1.stats_rows, k.cout, M, params, k.p_bn1, buffers, k.b_bn1, b.coef1, s));
     ECG_TRY(ecg_bn_act(dt, b.y1, b.coef1, nullptr, nullptr, nullptr, 1, 1, b.a1, M, k.cout, s));
-    ECG_TRY(ecg_conv_igemm(dt, 0, g2, b.a1, b.w2f, b.y2, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
-    ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, s));
+    ECG_TRY(ecg_conv_igemm(dt, 0, g2, b.a1, b.w2f, b.y2, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s, &e2));
+    ECG_TRY(bn_coef(r, w.stats, e2.stats_rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, s));
     if (k.down) {
       ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
       ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
@@ -362,20 +368,48 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       ConvGeom g2 = make_geom(N, k.hout, k.wout, k.cout, k.cout, 3, 3, 1, 1, 1);
       const int pp = st & 1;  // which of the two dy / dy1 / dyd buffers (and their reader events) this block uses
       void *dyb = q.dy[pp], *dy1b = q.dy1[pp], *dydb = q.dyd[pp];
+      // The REDUCTION pass of a BatchNorm backward is fused into the epilogue of the dgrad that produces its input,
+      // wherever that dgrad runs on the halo kernel (ConvEpi): bn1's into this block's conv2 dgrad; bn2's into the conv1
+      // dgrad of the NEXT block (processed one stage earlier), which then also stores the gradient already masked by
+      // this block's ReLU -- that buffer IS dz.  Pure function of the geometry, so stage ranges may be split across calls.
+      bool fused2 = false;
+      int fused2_rows = 0;
+      // (ECGMM_BN_FUSE=0: always the separate reduction pass -- A/B switch; same results up to fp32 summation order)
+      static const bool fuse_on = [] { const char* e = getenv("ECGMM_BN_FUSE"); return !(e && e[0] == '0'); }();
+      if (fuse_on && i + 1 < 8 && !r.blk[i + 1].down) {
+        const BlockCfg& kn = r.blk[i + 1];
+        const ConvGeom gn = make_geom(N, kn.hin, kn.win, kn.cin, kn.cout, 3, 3, 1, 1, 1);
+        fused2 = ecg_conv_halo_ok(dt, 1, gn);
+        fused2_rows = fused2 ? ecg_conv_halo_rows(1, gn) : 0;
+      }
       // out = relu(bn2(y2) + identity)
       main_wait(s, g_side.done2[0][pp]);  // the wgrad2 of two blocks ago has finished reading this dy buffer
-      ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, nullptr, nullptr, 1, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
-                         G(grads, k.p_bn2 + 1), dyb, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
+      const void* dzp = q.dz;
+      if (fused2) {
+        dzp = dcur;
+        ECG_TRY(ecg_bn_bwd_tail(dt, dcur, nullptr, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
+                                G(grads, k.p_bn2 + 1), dyb, q.red2, fused2_rows, M, k.cout, q.bn_scratch, s));
+      } else {
+        ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, nullptr, nullptr, 1, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
+                           G(grads, k.p_bn2 + 1), dyb, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
+      }
       if (G(grads, k.p_conv2)) {
         if (side) side_fork(s);
         ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, dyb, G(grads, k.p_conv2), 0, q.wg_ws, q.wg_bytes, ws));
         if (side) g_side.done2[0][pp] = side_mark();
       }
-      ECG_TRY(ecg_conv_igemm(dt, 1, g2, dyb, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s));
       // a1 = relu(bn1(y1)); the mask is recomputed from y1
+      ConvEpi ea = {};
+      if (fuse_on) { ea.wg_rows = 1; ea.red_y = b.y1; ea.red_mask = b.y1; ea.red_coef = b.coef1; ea.red_rows = q.red1; }
+      ECG_TRY(ecg_conv_igemm(dt, 1, g2, dyb, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s, &ea));
       main_wait(s, g_side.done2[1][pp]);
-      ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
-                         G(grads, k.p_bn1 + 1), dy1b, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
+      if (ea.red_done) {
+        ECG_TRY(ecg_bn_bwd_tail(dt, q.da, b.y1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
+                                G(grads, k.p_bn1 + 1), dy1b, q.red1, ea.red_rows_n, M, k.cout, q.bn_scratch, s));
+      } else {
+        ECG_TRY(ecg_bn_bwd(dt, q.da, b.y1, nullptr, nullptr, 1, b.y1, b.coef1, P(params, k.p_bn1), G(grads, k.p_bn1),
+                           G(grads, k.p_bn1 + 1), dy1b, nullptr, nullptr, M, k.cout, q.bn_scratch, s));
+      }
       if (G(grads, k.p_conv1)) {
         if (side) side_fork(s);
         ECG_TRY(ecg_conv_wgrad(dt, g1, in, dy1b, G(grads, k.p_conv1), 0, q.wg_ws, q.wg_bytes, ws));
@@ -384,7 +418,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       if (k.down) {
         ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
         main_wait(s, g_side.done2[2][pp]);
-        ECG_TRY(ecg_bn_bwd(dt, q.dz, nullptr, nullptr, nullptr, 1, b.yd, b.coefd, P(params, k.p_dbn),
+        ECG_TRY(ecg_bn_bwd(dt, dzp, nullptr, nullptr, nullptr, 1, b.yd, b.coefd, P(params, k.p_dbn),
                            G(grads, k.p_dbn), G(grads, k.p_dbn + 1), dydb, nullptr, nullptr, M, k.cout, q.bn_scratch,
                            s));
         if (G(grads, k.p_dconv)) {
@@ -395,7 +429,13 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
         ECG_TRY(ecg_conv_igemm(dt, 1, gd, dydb, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
         ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
       } else {
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
+        // this conv1 dgrad produces the previous block's output gradient: fuse that block's bn2 reduction (see above)
+        ConvEpi eb = {};
+        if (fuse_on && i > 0 && ecg_conv_halo_ok(dt, 1, g1)) {
+          const FwdWs::B& pb = w.b[i - 1];
+          eb.wg_rows = 1; eb.red_y = pb.y2; eb.red_mask = pb.out; eb.red_coef = pb.coef2; eb.red_rows = q.red2;
+        }
+        ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, dzp, nullptr, 0, s, &eb));
       }
     } else if (st == 9) {
       const void* dp0 = q.X[8 & 1];

@@ -166,6 +166,21 @@ int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* 
                  int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma,
                  float* dbeta, void* dy, void* dz_out, float* dbias, int64_t M, int C, void* scratch, void* stream);
 
+/* The same backward with its reduction pass fused into the convolution that PRODUCES dout (autograd of
+ * conv -> BatchNorm -> ReLU chains: torchvision BasicBlock, multimodal_paper_modal_balance.py:210; train.py:80):
+ * ecgmm_conv_bwd_data_bnred is ecgmm_conv_bwd_data that also accumulates, in its epilogue, the partial rows
+ * (sum g, sum g * (bn_y - mean)) of g = [mask] * dx over the pixels, bn_mask == bn_y (or NULL): mask = (bn(bn_y) > 0)
+ * and dx is stored unmasked; otherwise mask = (bn_mask > 0) and dx is stored MASKED.  rows: room for 256 x [2][Cin]
+ * floats.  *nrows = rows written, or 0 when this geometry is not served by the fused kernel (dx is then the plain
+ * gradient and the caller runs ecgmm_bn_bwd).  ecgmm_bn_bwd_from_rows finishes the backward from such rows
+ * (finalize + apply; maskref as in ecgmm_bn_bwd, NULL for an already masked dout). */
+int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
+                              const void* addend, void* dx, const void* bn_y, const void* bn_mask, const float* bn_coef,
+                              float* rows, int* nrows, void* stream);
+int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
+                           const float* gamma, float* dgamma, float* dbeta, void* dy, const float* rows, int nrows,
+                           int64_t M, int C, void* scratch, void* stream);
+
 /* relu(bn(y)) -> MaxPool(3,2,1) (resnet18.maxpool; ResNet1D_SE.initial[3], PMB:103) and its backward */
 int ecgmm_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int N, int H, int W,
                          int C, void* stream);

@@ -141,6 +141,74 @@ def test_conv_halo_kernel_agrees_with_the_general_kernel():
     assert (outs[0][0] >= 0).all()           # act = ReLU in the epilogue
 
 
+@pytest.mark.parametrize("sep_mask", [False, True])
+@pytest.mark.parametrize("case", [(8, 16, 16, 128, 128), (16, 8, 8, 256, 64), (4, 8, 8, 64, 128)])
+def test_dgrad_with_fused_batchnorm_backward_reduction(case, sep_mask):
+    """conv dgrad whose epilogue also reduces for the BatchNorm backward that consumes the gradient
+    (ecgmm_conv_bwd_data_bnred + ecgmm_bn_bwd_from_rows) == plain dgrad + ecgmm_bn_bwd == torch autograd of
+    relu(bn(y) [+ res]) -> conv.  sep_mask: the ReLU followed a residual add, so its mask comes from the block output
+    (BasicBlock tail) and the stored gradient is the masked one."""
+    N, H, W, Cin, Cout = case
+    lib = L.lib()
+    dt = L.BF16
+    M = N * H * W
+    d = conv_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    y = bf16_round(fill.hash_tensor((N, Cin, H, W), 51, 2.0) + 0.3)          # raw conv output that BN normalises
+    res = bf16_round(fill.hash_tensor((N, Cin, H, W), 52))
+    w = bf16_round(fill.hash_tensor((Cout, Cin, 3, 3), 53, 0.05))
+    dy = bf16_round(fill.hash_tensor((N, Cout, H, W), 54))
+    gam, bet = 1 + 0.2 * fill.hash_tensor((Cin,), 55), 0.1 * fill.hash_tensor((Cin,), 56)
+    yg, dyg = to_nhwc(y, dt), to_nhwc(dy, dt)
+    _, wd = pack_weight(w, dt)
+    # forward coefficients + activated tensor on the GPU (bn_finalize + bn_act), exactly what the plans feed the backward
+    rows = lib.ecgmm_col_stats_rows(dt, M, Cin)
+    part = torch.zeros(rows + 64, 2, Cin, device=DEV)
+    L.check(lib.ecgmm_col_stats(dt, ptr(yg), M, Cin, ptr(part), stream()))
+    coef = torch.empty(4, Cin, device=DEV)
+    gg, bg = dev(gam), dev(bet)
+    L.check(lib.ecgmm_bn_finalize(ptr(part), rows, Cin, float(M), ptr(gg), ptr(bg), None, None, None, 0.1, 1e-5, ptr(coef), stream()))
+    resg = to_nhwc(res, dt) if sep_mask else None
+    outg = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+    L.check(lib.ecgmm_bn_act(dt, ptr(yg), ptr(coef), ptr(resg), None, None, 1, 1, ptr(outg), M, Cin, stream()))
+    mask = outg if sep_mask else yg
+    scratch = torch.empty(lib.ecgmm_bn_bwd_scratch(dt, M, Cin), device=DEV, dtype=torch.uint8)
+
+    def run(fused):
+        dx = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+        dyo = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+        dgam, dbet = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+        if fused:
+            rows_buf = torch.full((256, 2, Cin), float("nan"), device=DEV)
+            n = C.c_int(0)
+            L.check(lib.ecgmm_conv_bwd_data_bnred(dt, C.byref(d), ptr(dyg), ptr(wd), None, ptr(dx), ptr(yg), ptr(mask), ptr(coef),
+                                                  ptr(rows_buf), C.byref(n), stream()))
+            assert 1 <= n.value <= 256
+            L.check(lib.ecgmm_bn_bwd_from_rows(dt, ptr(dx), None if sep_mask else ptr(yg), ptr(yg), ptr(coef), ptr(gg), ptr(dgam),
+                                               ptr(dbet), ptr(dyo), ptr(rows_buf), n.value, M, Cin, ptr(scratch), stream()))
+        else:
+            dz = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+            L.check(lib.ecgmm_conv_bwd_data(dt, C.byref(d), ptr(dyg), ptr(wd), None, ptr(dx), stream()))
+            L.check(lib.ecgmm_bn_bwd(dt, ptr(dx), ptr(mask), None, None, 1, ptr(yg), ptr(coef), ptr(gg), ptr(dgam), ptr(dbet),
+                                     ptr(dyo), ptr(dz) if sep_mask else None, None, M, Cin, ptr(scratch), stream()))
+        torch.cuda.synchronize()
+        return from_nhwc(dyo, dt, y.shape), dgam.cpu(), dbet.cpu()
+
+    try:
+        lib.ecgmm_conv_halo_enable(2)
+        a = run(True)
+        b = run(False)
+    finally:
+        lib.ecgmm_conv_halo_enable(1)
+    for u, v in zip(a, b):
+        assert rel_err(u, v) < 2e-3
+    # and against torch autograd (bf16 storage of the conv gradient is part of both GPU paths: loose tolerance)
+    yr, gr, br = y.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    z = F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)
+    act = F.relu(z + res) if sep_mask else F.relu(z)
+    F.conv2d(act, w, None, stride=1, padding=1).backward(dy)
+    assert rel_err(a[0], yr.grad) < 2e-2 and rel_err(a[1], gr.grad) < 1e-2 and rel_err(a[2], br.grad) < 1e-2
+
+
 def test_conv_rejects_bad_shapes():
     lib = L.lib()
     d = conv_desc(1, 8, 8, 6, 64, 3, 3, 1, 1, 1)   # Cin not a multiple of the 16-byte vector

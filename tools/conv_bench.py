@@ -8,7 +8,7 @@ from ecgmm.hip.functional import ptr, stream
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
-ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--only", default="fwd,dgrad,wgrad")
 ap.add_argument("--layers", default="")
 ap.add_argument("--dtype", default="bf16")
