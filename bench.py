@@ -115,7 +115,7 @@ def build(args, device):
                  torch.randn(B, 16, generator=g))
 
         def loss_fn(out, y):   # train.py:69-78
-            return HF.cross_entropy(out[3], y) + 0.1 * out[4]
+            return HF.cross_entropy_plus(out[3], y, out[4], 0.1)
     elif args.workload == "image_only":
         from ecgmm.train_image_only import ImageOnlyClassifier
         model = ImageOnlyClassifier(compute_dtype=args.dtype)

@@ -175,11 +175,19 @@ int ecgmm_varloss_bwd(const float* f, int B, int D, const float* gout, const flo
 
 int ecgmm_ce_fwd(const float* logits, const int64_t* labels, int B, int C, int focal, float alpha, float gamma,
                  float* loss, float* dcoef, void* stream) {
-  return ecg_ce_fwd(logits, (const long long*)labels, B, C, focal, alpha, gamma, loss, dcoef, S_(stream));
+  return ecg_ce_fwd(logits, (const long long*)labels, B, C, focal, alpha, gamma, loss, dcoef, nullptr, 0.f, S_(stream));
+}
+int ecgmm_ce_plus_fwd(const float* logits, const int64_t* labels, int B, int C, const float* extra, float extra_w,
+                      float* loss, float* dcoef, void* stream) {
+  return ecg_ce_fwd(logits, (const long long*)labels, B, C, 0, 1.f, 0.f, loss, dcoef, extra, extra_w, S_(stream));
+}
+int ecgmm_ce_plus_bwd(const float* logits, const int64_t* labels, int B, int C, const float* dcoef, const float* gout,
+                      float* dlogits, float* dextra, float extra_w, void* stream) {
+  return ecg_ce_bwd(logits, (const long long*)labels, B, C, dcoef, gout, dlogits, dextra, extra_w, S_(stream));
 }
 int ecgmm_ce_bwd(const float* logits, const int64_t* labels, int B, int C, const float* dcoef, const float* gout,
                  float* dlogits, void* stream) {
-  return ecg_ce_bwd(logits, (const long long*)labels, B, C, dcoef, gout, dlogits, S_(stream));
+  return ecg_ce_bwd(logits, (const long long*)labels, B, C, dcoef, gout, dlogits, nullptr, 0.f, S_(stream));
 }
 
 int ecgmm_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset,

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void varloss_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits,
                                                       const long long* __restrict__ labels, int B, int C, int focal,
-                                                      float alpha, float gamma, float* loss, float* dcoef) {
+                                                      float alpha, float gamma, float* loss, float* dcoef,
+                                                      const float* __restrict__ extra, float extra_w) {
   // dcoef[b] = dLoss/dCE_b (before the 1/B), consumed by the backward kernel
   __shared__ float sh[256];
   float acc = 0.f;
@@ -357,13 +358,15 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *loss = sh[0] / (float)B;
+  // (+ extra_w * extra: the step loss of train.py:78, CE(fusion_logits) + 0.1 * var_loss, without two more launches)
+  if (threadIdx.x == 0) *loss = sh[0] / (float)B + (extra ? extra_w * extra[0] : 0.f);
 }
 
 __global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, int B, int C,
                               const float* __restrict__ dcoef, const float* __restrict__ gout,
-                              float* __restrict__ dlogits) {
+                              float* __restrict__ dlogits, float* __restrict__ dextra, float extra_w) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dextra && b == 0) dextra[0] = gout[0] * extra_w;
   if (b >= B) return;
   const float* z = logits + (size_t)b * C;
   float m = z[0];
@@ -567,15 +570,16 @@ int ecg_varloss_bwd(const float* f, int B, int D, const float* gout, const float
 }
 
 int ecg_ce_fwd(const float* logits, const long long* labels, int B, int C, int focal, float alpha, float gamma,
-               float* loss, float* dcoef, hipStream_t s) {
-  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, logits, labels, B, C, focal, alpha, gamma, loss, dcoef);
+               float* loss, float* dcoef, const float* extra, float extra_w, hipStream_t s) {
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, logits, labels, B, C, focal, alpha, gamma, loss, dcoef,
+                     extra, extra_w);
   ECG_CHECK_LAUNCH("ce_fwd");
   return 0;
 }
 int ecg_ce_bwd(const float* logits, const long long* labels, int B, int C, const float* dcoef, const float* gout,
-               float* dlogits, hipStream_t s) {
+               float* dlogits, float* dextra, float extra_w, hipStream_t s) {
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, logits, labels, B, C, dcoef, gout,
-                     dlogits);
+                     dlogits, dextra, extra_w);
   ECG_CHECK_LAUNCH("ce_bwd");
   return 0;
 }

@@ -100,9 +100,9 @@ int ecg_varloss_fwd(const float* f0, const float* f1, const float* f2, int B, in
 int ecg_varloss_bwd(const float* f, int B, int D, const float* gout, const float* scratch, int m, float* df,
                     int accumulate, hipStream_t s);
 int ecg_ce_fwd(const float* logits, const long long* labels, int B, int C, int focal, float alpha, float gamma,
-               float* loss, float* dcoef, hipStream_t s);
+               float* loss, float* dcoef, const float* extra, float extra_w, hipStream_t s);
 int ecg_ce_bwd(const float* logits, const long long* labels, int B, int C, const float* dcoef, const float* gout,
-               float* dlogits, hipStream_t s);
+               float* dlogits, float* dextra, float extra_w, hipStream_t s);
 int ecg_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed,
                     unsigned long long offset, hipStream_t s);
 int ecg_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, hipStream_t s);

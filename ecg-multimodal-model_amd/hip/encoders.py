@@ -117,3 +117,74 @@ class ResNet1DSpec(PlanSpec):
 
 def run_plan(x, spec, params):
     return _PlanFn.apply(x, spec, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# The multimodal head (csrc/plan_head.hip): LayerNorms, branch heads, AttentionFusion, fusion classifier, var_loss
+# as ONE native call per direction.      reference: PMB:326-354, multimodal.py:440-469
+# --------------------------------------------------------------------------------------------
+class HeadFn(torch.autograd.Function):
+    """inputs: the three encoder outputs, a HeadSpec, the 19 head parameters (order of include/ecgmm.h).
+    outputs: img_logits, signal_logits, clinical_logits, fusion_logits, var_loss, soft_weights"""
+
+    @staticmethod
+    def forward(ctx, img_raw, sig_raw, clin_raw, spec, *params):
+        raws = tuple(f32c(t) for t in (img_raw, sig_raw, clin_raw))
+        for t in raws + tuple(params):
+            _require_cuda(t, "multimodal head")
+        if len(params) != 19:
+            raise RuntimeError(f"multimodal head expects 19 parameters, got {len(params)}")
+        B = raws[0].shape[0]
+        dims = [t.shape[1] for t in raws]
+        drop = spec.training and spec.dropout_p > 0
+        seed, off = _PhiloxState.take(B * spec.hidden) if drop else (0, 0)
+        desc = L.HeadDesc(B, (C.c_int * 3)(*dims), spec.hidden, spec.num_classes, int(spec.training), spec.eps,
+                          spec.dropout_p if drop else 0.0, seed, off)
+        lib = L.lib()
+        nb = lib.ecgmm_head_fwd_workspace(C.byref(desc))
+        if nb == 0:
+            L.check(1, "multimodal head workspace query")
+        dev = raws[0].device
+        ws = new_bytes(nb, dev)
+        logits = [torch.empty(B, spec.num_classes, device=dev, dtype=torch.float32) for _ in range(4)]
+        var = torch.empty((), device=dev, dtype=torch.float32)
+        soft = torch.empty(3, device=dev, dtype=torch.float32)
+        L.check(lib.ecgmm_head_forward(C.byref(desc), _table(raws), _table(params), _table(logits), ptr(var), ptr(soft),
+                                       ptr(ws), ws.numel(), stream()), "multimodal head forward")
+        ctx.desc, ctx.ws, ctx.raws, ctx.params = desc, ws, raws, params
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(soft)
+        return (*logits, var, soft)
+
+    @staticmethod
+    def backward(ctx, g_img, g_sig, g_clin, g_fus, g_var, _g_soft):
+        desc, params = ctx.desc, ctx.params
+        lib = L.lib()
+        dlog = [None if g is None else f32c(g) for g in (g_img, g_sig, g_clin, g_fus)]
+        dvar = None if g_var is None else f32c(g_var).reshape(1)
+        fus = dlog[3] is not None
+        reach = [fus or dvar is not None or dlog[m] is not None for m in range(3)]   # any gradient reaches feat_m?
+        draw = [torch.empty_like(ctx.raws[m]) if ctx.needs_input_grad[m] else None for m in range(3)]
+        # a parameter gets a gradient only if its branch is part of the loss (train.py:78 leaves the three branch heads
+        # out: torch then leaves their .grad None, and so does this -- the sinks of skipped branches are not touched)
+        active = [reach[0], reach[0], reach[1], reach[1], reach[2], reach[2]]
+        active += [dlog[0] is not None] * 2 + [dlog[1] is not None] * 2 + [dlog[2] is not None] * 2
+        active += [fus] * 7
+        sinks = [grad_sink(p) if (a and ctx.needs_input_grad[4 + i]) else None
+                 for i, (p, a) in enumerate(zip(params, active))]
+        nb = lib.ecgmm_head_bwd_workspace(C.byref(desc))
+        bws = _Scratch.get("head_bwd", nb, ctx.raws[0].device)
+        L.check(lib.ecgmm_head_backward(C.byref(desc), _table(ctx.raws), _table(params), _table(sinks), _table(dlog),
+                                        ptr(dvar), _table(draw), ptr(ctx.ws), ptr(bws), bws.numel(), stream()),
+                "multimodal head backward")
+        ctx.ws = None
+        return (*draw, None) + (None,) * len(params)
+
+
+class HeadSpec:
+    def __init__(self, hidden, num_classes, training, eps, dropout_p):
+        self.hidden, self.num_classes, self.training, self.eps, self.dropout_p = hidden, num_classes, training, eps, dropout_p
+
+
+def run_head(img_raw, sig_raw, clin_raw, spec, params):
+    return HeadFn.apply(img_raw, sig_raw, clin_raw, spec, *params)

@@ -269,8 +269,46 @@ class CELossFn(torch.autograd.Function):
         return d, None, None, None, None
 
 
+class CEPlusFn(torch.autograd.Function):
+    """CrossEntropy(logits, labels) + w * extra  (the step loss of train.py:69-78: CE(fusion_logits) + 0.1 * var_loss)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, extra, w):
+        _require_cuda(logits, "cross_entropy")
+        logits, extra = f32c(logits), f32c(extra).reshape(1)
+        labels = labels.to(torch.int64).contiguous()
+        B, Cn = logits.shape
+        if labels.shape != (B,):
+            raise ValueError(f"cross_entropy: expected {B} class indices, got shape {tuple(labels.shape)}")
+        if _CHECK_LABELS and B > 0 and (int(labels.min()) < 0 or int(labels.max()) >= Cn):
+            raise IndexError("Target is out of bounds.")
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dcoef = torch.empty(B, device=logits.device, dtype=torch.float32)
+        L.check(L.lib().ecgmm_ce_plus_fwd(ptr(logits), ptr(labels), B, Cn, ptr(extra), float(w), ptr(loss), ptr(dcoef),
+                                          stream()), "ce_plus_fwd")
+        ctx.w = float(w)
+        ctx.save_for_backward(logits, labels, dcoef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, dcoef = ctx.saved_tensors
+        B, Cn = logits.shape
+        d = torch.empty_like(logits)
+        dextra = torch.empty((), device=logits.device, dtype=torch.float32)
+        gout = f32c(gout).reshape(1)
+        L.check(L.lib().ecgmm_ce_plus_bwd(ptr(logits), ptr(labels), B, Cn, ptr(dcoef), ptr(gout), ptr(d), ptr(dextra),
+                                          ctx.w, stream()), "ce_plus_bwd")
+        return d, None, dextra, None
+
+
 def cross_entropy(logits, labels):
     return CELossFn.apply(logits, labels, False, 1.0, 0.0)
+
+
+def cross_entropy_plus(logits, labels, extra, weight):
+    """CrossEntropy(logits, labels) + weight * extra in one kernel per direction"""
+    return CEPlusFn.apply(logits, labels, extra, weight)
 
 
 def focal_loss(logits, labels, alpha=1.0, gamma=2.0):

@@ -33,6 +33,11 @@ class ResNet1DDesc(C.Structure):
                 ("bn_momentum", f32), ("bn_eps", f32), ("dropout_p", f32), ("seed", u64), ("offset", u64)]
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [("B", i32), ("dim", i32 * 3), ("hidden", i32), ("num_classes", i32), ("training", i32),
+                ("ln_eps", f32), ("dropout_p", f32), ("seed", u64), ("offset", u64)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes).  Must list every function declared in include/ecgmm.h
 # (tests/test_abi.py parses the header and checks the two agree).
@@ -43,6 +48,10 @@ SIGNATURES = {
     "ecgmm_resnet18_bwd_workspace": (sz, [P(ResNet18Desc)]),
     "ecgmm_resnet18_forward": (i32, [P(ResNet18Desc), vp, P(vp), P(vp), vp, vp, sz, vp]),
     "ecgmm_resnet18_backward": (i32, [P(ResNet18Desc), vp, vp, P(vp), P(vp), vp, vp, sz, i32, i32, vp]),
+    "ecgmm_head_fwd_workspace": (sz, [P(HeadDesc)]),
+    "ecgmm_head_bwd_workspace": (sz, [P(HeadDesc)]),
+    "ecgmm_head_forward": (i32, [P(HeadDesc), P(vp), P(vp), P(vp), vp, vp, vp, sz, vp]),
+    "ecgmm_head_backward": (i32, [P(HeadDesc), P(vp), P(vp), P(vp), P(vp), vp, P(vp), vp, vp, sz, vp]),
     "ecgmm_conv_halo_enable": (i32, [i32]),
     "ecgmm_side_wgrad": (i32, [i32]),
     "ecgmm_side_defer_join": (i32, [i32]),
@@ -92,6 +101,8 @@ SIGNATURES = {
     "ecgmm_varloss_bwd": (i32, [vp, i32, i32, vp, vp, i32, vp, i32, vp]),
     "ecgmm_ce_fwd": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
     "ecgmm_ce_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+    "ecgmm_ce_plus_fwd": (i32, [vp, vp, i32, i32, vp, f32, vp, vp, vp]),
+    "ecgmm_ce_plus_bwd": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, f32, vp]),
     "ecgmm_dropout_fwd": (i32, [vp, vp, vp, i64, f32, u64, u64, vp]),
     "ecgmm_dropout_bwd": (i32, [vp, vp, vp, i64, f32, vp]),
     "ecgmm_adam": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]),

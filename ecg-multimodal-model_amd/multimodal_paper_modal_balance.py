@@ -214,6 +214,41 @@ class ECGMultimodalModel(nn.Module):
             image_raw = self.image_encoder(image)
             signal_raw = self.signal_encoder(ecg_signal)
             clinical_raw = self._clinical_forward(clinical)
+        spec = self._head_spec()
+        if spec is not None and image_raw.is_cuda:
+            # everything after the encoders as ONE native call per direction (csrc/plan_head.hip): the same kernels as
+            # the module-by-module path below, without ~85 autograd nodes' worth of host work between the encoders'
+            # forward and backward, where no stream has anything else queued
+            return E.run_head(image_raw, signal_raw, clinical_raw, spec, self._head_params())
+        return self._head_by_modules(image_raw, signal_raw, clinical_raw)
+
+    def _head_params(self):
+        fc = self.fusion_classifier
+        return [self.image_norm.weight, self.image_norm.bias, self.signal_norm.weight, self.signal_norm.bias,
+                self.clinical_norm.weight, self.clinical_norm.bias,
+                self.image_classifier.weight, self.image_classifier.bias, self.signal_classifier.weight,
+                self.signal_classifier.bias, self.clinical_classifier.weight, self.clinical_classifier.bias,
+                self.attention_fusion.weights, self.attention_fusion.norm.weight, self.attention_fusion.norm.bias,
+                fc[0].weight, fc[0].bias, fc[3].weight, fc[3].bias]
+
+    def _head_spec(self):
+        """launch description of the fused head, or None when the module tree is not the reference's
+        Linear-ReLU-Dropout-Linear / LayerNorm layout (then the modules run one by one)"""
+        fc = self.fusion_classifier
+        norms = (self.image_norm, self.signal_norm, self.clinical_norm, self.attention_fusion.norm)
+        ok = (len(fc) == 4 and isinstance(fc[0], hnn.Linear) and isinstance(fc[1], nn.ReLU)
+              and isinstance(fc[2], nn.Dropout) and isinstance(fc[3], hnn.Linear)
+              and all(isinstance(n, hnn.LayerNorm) and n.eps == norms[0].eps for n in norms)
+              and all(getattr(m, "bias", None) is not None for m in (fc[0], fc[3], self.image_classifier,
+                                                                      self.signal_classifier, self.clinical_classifier))
+              and getattr(self.config, "fused_head", True))
+        if not ok:
+            return None
+        drop = fc[2]
+        return E.HeadSpec(fc[0].out_features, fc[3].out_features, bool(self.training and drop.training), norms[0].eps,
+                          float(drop.p))
+
+    def _head_by_modules(self, image_raw, signal_raw, clinical_raw):
         img_feat = self.image_norm(image_raw)
         signal_feat = self.signal_norm(signal_raw)
         clinical_feat = self.clinical_norm(clinical_raw)

@@ -35,7 +35,7 @@ def _writer(logdir):
 def step_loss(outputs, labels):
     """train.py:69-78: total = CE(fusion_logits) + 0.1 * var_loss (branch CE terms are computed by the
     reference but not part of total_loss)."""
-    return HF.cross_entropy(outputs[3], labels) + 0.1 * outputs[4]
+    return HF.cross_entropy_plus(outputs[3], labels, outputs[4], 0.1)
 
 
 def run_epoch(model, loader, device, optimizer=None):

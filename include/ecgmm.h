@@ -97,6 +97,37 @@ int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float* signal, c
                             const void* const* params, void* const* grads, void* ws_fwd, void* ws_bwd,
                             size_t ws_bwd_bytes, int stage_begin, int stage_end, void* stream);
 
+/* The multimodal head: everything ECGMultimodalModel.forward does after the three encoders, as ONE call per
+ * direction (PMB:326-354 / multimodal.py:440-469: three LayerNorms, three branch Linear heads, AttentionFusion,
+ * fusion_classifier = Linear-ReLU-Dropout-Linear, var_loss).  Same kernels as the per-op entry points below.
+ * params (19, fp32): image_norm.{weight,bias}, signal_norm.{..}, clinical_norm.{..}, image_classifier.{weight,bias},
+ * signal_classifier.{..}, clinical_classifier.{..}, attention_fusion.weights, attention_fusion.norm.{weight,bias},
+ * fusion_classifier.0.{weight,bias}, fusion_classifier.3.{weight,bias}.
+ * raw[3]: encoder outputs [B, dim[m]];  logits[4]: image / signal / clinical / fusion logits [B, num_classes];
+ * var_loss: scalar;  soft_w: softmax of the 3 fusion weights. */
+#define ECGMM_HEAD_NPARAMS 19
+typedef struct {
+  int B;
+  int dim[3];        /* image_dim, signal_dim, clinical_dim (PMB:203-206: 256 each; multimodal.py:340-342: 512/128/32) */
+  int hidden;        /* fusion_classifier.0 out_features (128, PMB:284) */
+  int num_classes;
+  int training;      /* Dropout active (model.train()) */
+  float ln_eps;
+  float dropout_p;   /* fusion_classifier.2 = Dropout(0.3), PMB:287 */
+  uint64_t seed, offset;
+} ecgmm_head_desc;
+size_t ecgmm_head_fwd_workspace(const ecgmm_head_desc* d);
+size_t ecgmm_head_bwd_workspace(const ecgmm_head_desc* d);
+int ecgmm_head_forward(const ecgmm_head_desc* d, const float* const* raw, const void* const* params,
+                       float* const* logits, float* var_loss, float* soft_w, void* ws, size_t ws_bytes, void* stream);
+/* replaces the head part of total_loss.backward() (train.py:80).  dlogits[k] / dvar NULL = that output is not in the
+ * loss (train.py:78 uses only fusion_logits and var_loss): the branch is skipped, its grads[] entries are left
+ * untouched.  grads[i] NULL skips a parameter; draw[m] NULL = encoder m is frozen (train.py:35-40).  Gradients are
+ * WRITTEN, not accumulated. */
+int ecgmm_head_backward(const ecgmm_head_desc* d, const float* const* raw, const void* const* params,
+                        void* const* grads, const float* const* dlogits, const float* dvar, float* const* draw,
+                        void* ws_fwd, void* ws_bwd, size_t ws_bwd_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-op entry points (building blocks of the plans; also what the parity tests call one by one)
  * ------------------------------------------------------------------------------------------- */
@@ -222,6 +253,12 @@ int ecgmm_ce_fwd(const float* logits, const int64_t* labels, int B, int C, int f
                  float* loss, float* dcoef, void* stream);
 int ecgmm_ce_bwd(const float* logits, const int64_t* labels, int B, int C, const float* dcoef, const float* gout,
                  float* dlogits, void* stream);
+/* the step loss of train.py:69-78 in one launch per direction: loss = CrossEntropy(logits, labels) + extra_w * extra[0]
+ * (extra = var_loss, extra_w = 0.1); backward: dlogits and dextra[0] = gout * extra_w */
+int ecgmm_ce_plus_fwd(const float* logits, const int64_t* labels, int B, int C, const float* extra, float extra_w,
+                      float* loss, float* dcoef, void* stream);
+int ecgmm_ce_plus_bwd(const float* logits, const int64_t* labels, int B, int C, const float* dcoef, const float* gout,
+                      float* dlogits, float* dextra, float extra_w, void* stream);
 
 /* nn.Dropout (PMB:115,260,287): Philox4x32-10, keep-mask bytes saved for the backward */
 int ecgmm_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset,

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from ecgmm.hip import encoders as E
 from ecgmm.hip import functional as HF
 from ecgmm.hip import lib as L
 from ecgmm.hip import nn as hnn
@@ -161,3 +162,88 @@ def test_dropout_statistics_and_backward():
     y2 = HF.dropout(x, 0.3, True)          # the Philox offset advanced: a different mask
     assert not torch.equal(y2.detach() != 0, y.detach() != 0)
     assert HF.dropout(x, 0.3, False) is x  # eval: identity
+
+
+@pytest.mark.parametrize("loss_kind", ["train_py", "all_heads", "branch_only"])
+def test_fused_head_plan_matches_modules_and_oracle(loss_kind):
+    """csrc/plan_head.hip (one native call per direction) == the module-by-module head == the oracle's head
+    (PMB:326-354): all six outputs, every parameter gradient, the gradients handed to the encoders; and heads that are not
+    in the loss (train.py:78 uses fusion_logits + var_loss only) keep grad None."""
+    from ecgmm.config import Config
+    from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+    from oracle import fill, ref_models as O
+    cfg = type("C", (Config,), {"clinical_input_dim": 16, "compute_dtype": "fp32"})
+    ref = O.disable_dropout(fill.hash_fill_module(O.ECGMultimodalModel(2, 16), "mm.")).train()
+    nets = []
+    for fused in (True, False):
+        c = type("Cf", (cfg,), {"fused_head": fused})
+        n = ECGMultimodalModel(c)
+        n.load_state_dict(ref.state_dict())
+        for m in n.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        nets.append(n.to(DEV).train())
+    B = 24
+    raws = [fill.hash_tensor((B, 256), 90 + i, 1.5) for i in range(3)]
+    lab = torch.arange(B) % 2
+
+    def loss_of(out, y, CE):
+        if loss_kind == "train_py":
+            return CE(out[3], y) + 0.1 * out[4]
+        if loss_kind == "all_heads":
+            return CE(out[0], y) + CE(out[1], y) + CE(out[2], y) + CE(out[3], y) + 0.1 * out[4]
+        return CE(out[1], y)
+
+    def ref_head(r):
+        f = [ref.image_norm(r[0]), ref.signal_norm(r[1]), ref.clinical_norm(r[2])]
+        fused, w = ref.attention_fusion(*f)
+        v = [torch.var(t, dim=1).mean() for t in f]
+        var = (v[0] - v[1]).abs() + (v[0] - v[2]).abs() + (v[1] - v[2]).abs()
+        return (ref.image_classifier(f[0]), ref.signal_classifier(f[1]), ref.clinical_classifier(f[2]),
+                ref.fusion_classifier(fused), var, w)
+
+    rr = [t.clone().requires_grad_(True) for t in raws]
+    out_ref = ref_head(rr)
+    loss_of(out_ref, lab, torch.nn.functional.cross_entropy).backward()
+    results = []
+    for n in nets:
+        rg = [dev(t).requires_grad_(True) for t in raws]
+        spec = n._head_spec()
+        out = E.run_head(*rg, spec, n._head_params()) if spec is not None else n._head_by_modules(*rg)
+        loss_of(out, dev(lab), HF.cross_entropy).backward()
+        torch.cuda.synchronize()
+        results.append((out, rg, n))
+    assert nets[0]._head_spec() is not None and nets[1]._head_spec() is None
+    for out, rg, n in results:
+        for a, b in zip(out, out_ref):
+            assert (a.detach().cpu() - b.detach()).abs().max() < 2e-5
+        for a, b in zip(rg, rr):
+            if b.grad is None:
+                assert a.grad is None or a.grad.abs().max() == 0
+            else:
+                assert rel_err(a.grad.cpu(), b.grad) < 1e-4
+        pr = dict(ref.named_parameters())
+        for k, p in n.named_parameters():
+            if "encoder" in k:
+                continue
+            if pr[k].grad is None:
+                assert p.grad is None, k
+            else:
+                assert p.grad is not None and rel_err(p.grad.cpu(), pr[k].grad) < 2e-4, k
+    # fused == unfused to fp32 rounding
+    for a, b in zip(results[0][0], results[1][0]):
+        assert (a - b).abs().max() < 1e-6
+
+
+def test_cross_entropy_plus_is_ce_plus_weighted_extra():
+    logits = dev(fill.hash_tensor((12, 2), 61, 2.0)).requires_grad_(True)
+    extra = dev(torch.tensor(0.37)).requires_grad_(True)
+    lab = dev(torch.arange(12) % 2)
+    loss = HF.cross_entropy_plus(logits, lab, extra, 0.1)
+    loss.backward()
+    lr = logits.detach().cpu().clone().requires_grad_(True)
+    er = torch.tensor(0.37, requires_grad=True)
+    ref = torch.nn.functional.cross_entropy(lr, lab.cpu()) + 0.1 * er
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 and rel_err(logits.grad.cpu(), lr.grad) < 1e-6
+    assert abs(extra.grad.item() - 0.1) < 1e-7
