@@ -8,6 +8,10 @@ TEST INFRASTRUCTURE ONLY.  What it pins:
   g5  oracle ECGMultimodalModel (restatement), B=8: eval/train outputs, grads, 3-step Adam losses
   g6  oracle ResNet18 (restatement of torchvision's): per-stage statistics
   g7  reference preprocess_signal / remove_baseline_drift on [12, 5000] float inputs    (imported)
+  g9  the REFERENCE's own ECGMultimodalModel classes (multimodal_paper_modal_balance.py and multimodal.py, imported
+      with stand-ins for the absent third-party packages / checkpoint files, see _import_reference_module): the
+      oracle is asserted bit-identical, the reference objects' outputs, gradients and 3-step Adam losses are stored;
+      `python oracle/make_golden.py g9` regenerates only this file
   g8  the image transform: Pillow's own BILINEAR resize (the arithmetic torchvision's Resize runs on a PIL
       picture; torchvision itself is absent here and unpinned in the reference) of formula pictures,
       + float32 ToTensor/Normalize; `python oracle/make_golden.py g8` regenerates only this file
@@ -58,10 +62,116 @@ def g8_image():
     np.savez_compressed(os.path.join(OUT, "g8_image.npz"), **g8)
 
 
+def _import_reference_module(name):
+    """Import one of the reference's own model files (/root/reference/<name>.py) in this container.  The file is
+    executed as it stands; what this image lacks -- third-party packages the file imports at module level and the
+    checkpoint files its constructor hard-loads, none of which is reference code -- is stood in for:
+      torchvision.models.resnet18()   -> oracle.ref_models.ResNet18 (the restatement; that sub-graph STAYS unpinned)
+      pytorch_tabnet TabNetNoEmbeddings -> oracle.tabnet_ref.TabNetNoEmbeddings (restatement; STAYS unpinned)
+      seaborn                           -> empty module (plot helper import only)
+      torch.load('./checkpoints/...')   -> {} (files not in the tree: multimodal_paper_modal_balance.py:215,234-237,
+                                           multimodal.py:350,369-372,388); load_state_dict(strict=False) then keeps the
+                                           hash-filled parameters
+    So what IS pinned to the reference's own code: AttentionFusion, the clinical MLP, the LayerNorms, branch heads,
+    fusion_classifier, forward's composition order and var_loss, and (again) ResNet1D_SE."""
+    import importlib
+    import types
+    from oracle import tabnet_ref as T
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tvm.resnet18 = lambda *a, **k: O.ResNet18()
+    tvm.ResNet18_Weights = type("ResNet18_Weights", (), {"IMAGENET1K_V1": None})
+    tv.models = tvm
+    pt, ptn = types.ModuleType("pytorch_tabnet"), types.ModuleType("pytorch_tabnet.tab_network")
+    ptn.TabNetNoEmbeddings = T.TabNetNoEmbeddings
+    pt.tab_network = ptn
+    for k, v in (("torchvision", tv), ("torchvision.models", tvm), ("pytorch_tabnet", pt),
+                 ("pytorch_tabnet.tab_network", ptn), ("seaborn", types.ModuleType("seaborn"))):
+        sys.modules.setdefault(k, v)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    return importlib.import_module(name)
+
+
+def g9_reference_composition():
+    """g9: the REFERENCE's ECGMultimodalModel objects (both variants), hash-filled, against the oracle: bit-identity of
+    the 6-tuple, the train.py loss and every gradient is asserted here; the reference objects' outputs are the golden."""
+    import contextlib
+    import io
+    real_load = torch.load
+
+    def fake_load(f, *a, **k):
+        if isinstance(f, str) and f.startswith("./checkpoints/"):
+            return {}
+        return real_load(f, *a, **k)
+
+    sys.path.insert(0, REF)
+    import config as RC                                   # the reference's Config (device = cpu here)
+    g9 = {}
+    for tag, modname, clin_in, make_oracle in (
+            ("pmb", "multimodal_paper_modal_balance", 24, lambda: O.ECGMultimodalModel(RC.Config.num_classes, 24)),
+            ("tab", "multimodal", 2, lambda: __import__("oracle.tabnet_ref", fromlist=["x"]).multimodal_tabnet_model(RC.Config.num_classes))):
+        mod = _import_reference_module(modname)
+        torch.load = fake_load
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref = mod.ECGMultimodalModel(RC.Config)
+        finally:
+            torch.load = real_load
+        mine = make_oracle()
+        assert list(ref.state_dict()) == list(mine.state_dict()), "state-dict keys differ from the reference object"
+        for m in (ref, mine):
+            fill.hash_fill_module(m, "mm.")
+            O.disable_dropout(m)
+        img, sig, clin, lab = fill.synthetic_batch(8, clin_dim=clin_in, salt=9)
+        outs = {}
+        for name, m in (("ref", ref), ("mine", mine)):
+            m.eval()
+            with torch.no_grad():
+                ev = m(img, sig, clin)
+            m.train()
+            m.zero_grad()
+            tr = m(img, sig, clin)
+            loss = F.cross_entropy(tr[3], lab) + 0.1 * tr[4]           # train.py:69-78
+            loss.backward()
+            outs[name] = (ev, tr, loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        for a, b in zip(outs["ref"][0] + outs["ref"][1], outs["mine"][0] + outs["mine"][1]):
+            assert torch.equal(a, b), f"{tag}: oracle output differs from the reference object's"
+        assert torch.equal(outs["ref"][2], outs["mine"][2])
+        assert outs["ref"][3].keys() == outs["mine"][3].keys()
+        for k in outs["ref"][3]:
+            assert torch.equal(outs["ref"][3][k], outs["mine"][3][k]), (tag, k)
+        names = ("img_logits", "sig_logits", "clin_logits", "fusion_logits", "var_loss", "soft_w")
+        for n, o in zip(names, outs["ref"][0]):
+            g9[f"{tag}.eval.{n}"] = npy(o)
+        for n, o in zip(names, outs["ref"][1]):
+            g9[f"{tag}.train.{n}"] = npy(o)
+        g9[f"{tag}.train.loss"] = npy(outs["ref"][2])
+        for k, g in outs["ref"][3].items():
+            g9[f"{tag}.gnorm.{k}"] = np.array(g.norm().item())
+            if "encoder" not in k or k.startswith("clinical_encoder"):
+                g9[f"{tag}.grad.{k}"] = npy(g)                          # every head / fusion / clinical gradient in full
+        # three Adam steps of the reference object (train_paper_modal_balance.py:29: all parameters trainable)
+        opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+        ls = []
+        for _ in range(3):
+            opt.zero_grad()
+            o = ref(img, sig, clin)
+            l = F.cross_entropy(o[3], lab) + 0.1 * o[4]
+            l.backward(); opt.step(); ls.append(l.item())
+        g9[f"{tag}.adam3"] = np.array(ls)
+        print(f"g9[{tag}]: reference {modname}.ECGMultimodalModel == oracle bit for bit "
+              f"({len(outs['ref'][3])} gradients); loss {outs['ref'][2].item():.6f}")
+    np.savez_compressed(os.path.join(OUT, "g9_reference_composition.npz"), **g9)
+
+
 def main():
     if sys.argv[1:] == ["g8"]:
         g8_image()
         print("g8 written")
+        return
+    if sys.argv[1:] == ["g9"]:
+        g9_reference_composition()
+        print("g9 written")
         return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -234,6 +344,7 @@ def main():
                         y_short=R12.preprocess_signal(x7s.astype(np.float32).astype(np.float64)),
                         baseline_removed=R12.remove_baseline_drift(x7.astype(np.float32).astype(np.float64)))
     g8_image()
+    g9_reference_composition()
     print("goldens written to", OUT)
     for f_ in sorted(os.listdir(OUT)):
         print(f"  {f_}: {os.path.getsize(os.path.join(OUT, f_)) / 1024:.0f} KiB")

@@ -168,6 +168,56 @@ def test_multimodal_eval_and_train_logits_vs_golden_g5(golden_dir, cd, tol):
             assert rel_err(dict(net.named_parameters())[k].grad.cpu(), torch.from_numpy(g5["grad." + k])) < 5e-3, k
 
 
+@pytest.mark.parametrize("tag", ["pmb", "tab"])
+def test_multimodal_vs_reference_object_golden_g9(golden_dir, tag):
+    """g9 = outputs, loss, gradients and 3-step Adam losses of the REFERENCE's own ECGMultimodalModel objects
+    (multimodal_paper_modal_balance.py:197-354 with its 24-wide clinical MLP; multimodal.py:333-469 with widths
+    512 / 128 / 32 and the TabNet branch), hash-filled -- oracle/make_golden.py imports the reference files themselves.
+    fp32 compute path: all six outputs within 1e-3, every head / fusion / clinical gradient, the loss trajectory."""
+    from ecgmm.multimodal import ECGMultimodalModel as TabVariant
+    from oracle import tabnet_ref as T
+    g9 = np.load(f"{golden_dir}/g9_reference_composition.npz")
+    cfg = type("Cfg", (Config,), {"compute_dtype": "fp32"})          # clinical width: the reference's own (24 / 2)
+    if tag == "pmb":
+        ref, net, clin_in = O.ECGMultimodalModel(2, 24), ECGMultimodalModel(cfg), 24
+    else:
+        ref, net, clin_in = T.multimodal_tabnet_model(2), TabVariant(cfg), 2
+    net.load_state_dict(fill.hash_fill_module(ref, "mm.").state_dict(), strict=True)
+    net = _disable_dropout(net).to(DEV)
+    img, sig, clin, lab = fill.synthetic_batch(8, clin_dim=clin_in, salt=9)
+    names = ("img_logits", "sig_logits", "clin_logits", "fusion_logits", "var_loss", "soft_w")
+    net.eval()
+    with torch.no_grad():
+        out = net(dev(img), dev(sig), dev(clin))
+    for n, o in zip(names, out):
+        assert (o.cpu() - torch.from_numpy(g9[f"{tag}.eval.{n}"])).abs().max() < 1e-3, n
+    net.train()
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        out = net(dev(img), dev(sig), dev(clin))
+        loss = HF.cross_entropy_plus(out[3], dev(lab), out[4], 0.1)
+        loss.backward()
+        if it == 0:
+            torch.cuda.synchronize()
+            for n, o in zip(names, out):
+                assert (o.detach().cpu() - torch.from_numpy(g9[f"{tag}.train.{n}"])).abs().max() < 1e-3, n
+            for k, p in net.named_parameters():
+                if k == "clinical_encoder.0.bias":      # feeds BatchNorm: true gradient 0, rounding noise on both sides
+                    assert p.grad.abs().max().item() < 1e-6
+                elif f"{tag}.grad.{k}" in g9.files:
+                    assert rel_err(p.grad.cpu(), torch.from_numpy(g9[f"{tag}.grad.{k}"])) < 5e-3, k
+                elif f"{tag}.gnorm.{k}" in g9.files and not any(s in k for s in SIG_BIAS_SKIP):
+                    gn = float(g9[f"{tag}.gnorm.{k}"])
+                    assert abs(p.grad.norm().item() - gn) < 5e-3 * gn + 1e-6, (k, p.grad.norm().item(), gn)
+                else:
+                    assert p.grad is None or any(s in k for s in SIG_BIAS_SKIP), k
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, g9[f"{tag}.adam3"], atol=2e-3), (losses, g9[f"{tag}.adam3"])
+
+
 @pytest.mark.parametrize("frozen", [False, True])
 def test_multimodal_three_adam_steps_vs_golden_g5(golden_dir, frozen):
     """train.py:60-81 step (zero_grad / forward / CE + 0.1 var / backward / Adam) x3, fp32."""

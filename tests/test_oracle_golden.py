@@ -151,3 +151,30 @@ def test_library_resize_tables_match_the_oracle_coefficients():
         want = np.concatenate([hb.reshape(-1), hk.reshape(-1), vb.reshape(-1), vk.reshape(-1)])
         assert np.array_equal(buf, want)
         assert lib.ecgmm_image_resize_tables(h, w, oh, ow, buf.ctypes.data_as(C.c_void_p), nb - 4) != 0
+
+
+def test_oracle_reproduces_the_reference_composition_golden_g9(golden_dir):
+    """g9 holds what the REFERENCE's own ECGMultimodalModel objects (multimodal_paper_modal_balance.py and multimodal.py,
+    imported in the build container by oracle/make_golden.py, where bit-identity with the oracle is asserted) return
+    for hash-filled weights: the oracle must reproduce them on this machine too."""
+    from oracle import tabnet_ref as T
+    g9 = np.load(f"{golden_dir}/g9_reference_composition.npz")
+    names = ("img_logits", "sig_logits", "clin_logits", "fusion_logits", "var_loss", "soft_w")
+    for tag, clin_in, make in (("pmb", 24, lambda: O.ECGMultimodalModel(2, 24)), ("tab", 2, lambda: T.multimodal_tabnet_model(2))):
+        m = O.disable_dropout(fill.hash_fill_module(make(), "mm."))
+        img, sig, clin, lab = fill.synthetic_batch(8, clin_dim=clin_in, salt=9)
+        m.eval()
+        with torch.no_grad():
+            ev = m(img, sig, clin)
+        for n, o in zip(names, ev):
+            assert torch.allclose(o, torch.from_numpy(g9[f"{tag}.eval.{n}"]), atol=2e-5), (tag, n)
+        m.train()
+        tr = m(img, sig, clin)
+        loss = F.cross_entropy(tr[3], lab) + 0.1 * tr[4]
+        loss.backward()
+        assert abs(loss.item() - float(g9[f"{tag}.train.loss"])) < 2e-5
+        for k, p in m.named_parameters():
+            key = f"{tag}.grad.{k}"
+            if key in g9.files:
+                ref = torch.from_numpy(g9[key])
+                assert (p.grad - ref).norm() <= 2e-4 * ref.norm() + 1e-7, (tag, k)
