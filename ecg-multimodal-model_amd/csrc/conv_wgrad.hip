@@ -312,6 +312,268 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad_ring_kernel: the same 64(co) x 64(ci) x all-taps tile and split-K, for stride-1 "same" convolutions (3x3 pad 1,
+// 1x3 pad 1) in bf16 -- with the x operand kept in a RING of pixel rows instead of one gathered tile per tap.
+//
+// In wgrad_kernel every K step (32 pixels) moves 1 + NT tiles = 40 KB through the CU's vector-memory path for 36 MFMAs per
+// wave (10 LDS-DMA pieces per wave and step: ~40 % of a step in the s_memtime stamps), and the NT x tiles are NT shifted
+// copies of (almost) the same pixels.  With stride 1 the source pixel of tap (r, s) for output pixel p is the flat pixel
+// p + (r - ph) * W + (s - pw) of the SAME channels-last tensor, so one window of consecutive pixel rows serves every
+// tap: a 256-row ring (32 KB) indexed by (flat pixel & 255) holds [p0 - HL, p0 + 32 + HL) and takes in 32 new rows per
+// step -- 2 pieces per wave and step instead of 10.  A tap that leaves the image reads a zero row instead (per-lane
+// address select; the ring row it would hit holds a neighbouring pixel).  Ring rows advance by 32 per step, which
+// leaves the bank swizzle (bits 0-3 of the row) unchanged: the 2 x NT fragment addresses of a lane are computed once
+// and only rotated (+4096 B mod 32 KB) per step.
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradRingParams {
+  const void* x;
+  const void* dy;
+  float* slab;
+  int H, W, Cin, Cout, pad_h;
+  int M;
+  int steps_per_split;
+  int HL, HLa;           // halo pixels (pad_h * W + 1) and the same rounded up to a multiple of 8
+  unsigned mul_hw, sh_hw, mul_w, sh_w;
+};
+
+constexpr int RING_ROWS = 256;
+constexpr int RING_BYTES = RING_ROWS * 128;
+constexpr int RING_D = 3;                      // fills run RING_D steps ahead of the step being computed
+constexpr int RING_NDY = RING_D + 1;           // dy stages (4 KB each)
+constexpr int RING_DY = RING_BYTES;
+constexpr int RING_ZERO = RING_DY + RING_NDY * 4096;  // one all-zero 128-byte row
+constexpr int RING_LDS = RING_ZERO + 128;
+
+// LDS-DMA as inline asm (M0 = LDS byte address of the wave's 1-KiB piece, saved and restored): hipcc does not see these
+// loads, so it neither drains them with an s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 (which it does for
+// the builtin: an intrinsic without memory operands "may alias" the LDS-DMA, conv_wgrad.hip notes) nor counts them --
+// the kernel retires them with its own counted s_waitcnt vmcnt(N) + s_barrier, RING_D steps after issue.
+__device__ __forceinline__ void ring_dma16(const u32x4& rsrc, unsigned lds_addr, unsigned voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voffset), "s"(lds_addr), "s"(rsrc)
+      : "memory");
+#endif
+}
+template <int N> __device__ __forceinline__ void ring_wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ u32x4 ring_rsrc(const void* ptr, size_t bytes) {
+  const unsigned long long a = (unsigned long long)ptr;
+  return (u32x4){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu)),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bytes), 0x00020000u};
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
+  using C = WgCfg<bf16_t>;
+  constexpr int R = NT / 3;  // filter rows (S == 3)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int wco = wave & 1, wci = wave >> 1;
+  const int ci_tiles = p.Cin / 64;
+  int tile_id = blockIdx.x, split = blockIdx.y;
+  if ((gridDim.y & 7) == 0 && gridDim.x > 1) {   // a split's tiles on one XCD (see wgrad_kernel)
+    const int NT_ = gridDim.x, L = blockIdx.y * NT_ + blockIdx.x;
+    const int k = L >> 3;
+    split = (L & 7) + 8 * (k / NT_);
+    tile_id = k % NT_;
+  }
+  const int co0 = (tile_id / ci_tiles) * 64, ci0 = (tile_id % ci_tiles) * 64;
+  const bf16_t* __restrict__ x = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ dy = (const bf16_t*)p.dy;
+  const int total_steps = (p.M + 31) / 32;
+  const int s_begin = split * p.steps_per_split;
+  const int s_end = min(total_steps, s_begin + p.steps_per_split);
+
+  f32x4 acc[NT][2][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid < 8) *reinterpret_cast<u32x4*>(smem + RING_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+
+  // ---- DMA bookkeeping (whole tensors are addressed from their start: the host keeps them under 2 GiB)
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const u32x4 rs_x = ring_rsrc(x, (size_t)p.M * p.Cin * 2), rs_dy = ring_rsrc(dy, (size_t)p.M * p.Cout * 2);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS address of smem[0]
+  const int lrow8 = lane >> 3;
+  const unsigned x_pix_bytes = (unsigned)p.Cin * 2u, dy_row_bytes = (unsigned)p.Cout * 2u;
+  const int P0 = s_begin * 32;
+  // dy: lane fills (row = wave*8 + lane/8, physical chunk lane%8) of the step's 32 x 64 tile
+  const int drow = wave * 8 + lrow8;
+  const unsigned dy_lane = (unsigned)(co0 + (((lane & 7) ^ C::swz(drow)) * 8)) * 2u;
+  // x ring: a piece is 8 consecutive flat pixels; piece rows are 8-aligned in the ring, so the swizzle is per lane
+  auto x_piece = [&](int q0) {   // q0: first flat pixel of the piece (multiple of 8, may be negative or >= M)
+    const int q = q0 + lrow8;
+    const int rrow = q & (RING_ROWS - 1);
+    const unsigned src = (unsigned)q * x_pix_bytes + (unsigned)(ci0 + (((lane & 7) ^ C::swz(rrow)) * 8)) * 2u;
+    ring_dma16(rs_x, lds0 + (unsigned)((q0 & (RING_ROWS - 1)) * 128), (q >= 0 && q < p.M) ? src : OOB);
+  };
+  auto dy_piece = [&](int stage, int step) {
+    const int pix = step * 32 + drow;
+    ring_dma16(rs_dy, lds0 + (unsigned)(RING_DY + stage * 4096 + wv * 1024), pix < p.M ? (unsigned)pix * dy_row_bytes + dy_lane : OOB);
+  };
+  // fill group of `step` (2 DMAs per wave): its dy tile, and the 32 ring rows it needs beyond the previous step's window
+  auto dma_step = [&](int stage, int step) {
+    dy_piece(stage, step);
+    x_piece(step * 32 + p.HLa + wv * 8);
+  };
+
+  // ---- fragment addresses.  Lane (fq, q = fr >> 2, pq = fr & 3) supplies the row address of k rows 8 fq + q (lo) and
+  // + 4 (hi) of a step; per tap the ring-relative byte address of the lo / hi source pixel at the split's first step.
+  const int fr = lane & 15, fq = lane >> 4;
+  const int q4 = fr >> 2, pq = fr & 3;
+  const int kl = 8 * fq + q4;
+  unsigned A_lo[NT], A_hi[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = t / 3, sx = t - r * 3;
+    const int d = (r - p.pad_h) * p.W + (sx - 1);
+    const int byte0 = wci * 64 + 8 * pq;
+    const int rl = (P0 + kl + d) & (RING_ROWS - 1), rh = (P0 + kl + 4 + d) & (RING_ROWS - 1);
+    A_lo[t] = (unsigned)(rl * 128 + ((((byte0 >> 4) ^ C::swz(rl))) << 4) + (byte0 & 15));
+    A_hi[t] = (unsigned)(rh * 128 + ((((byte0 >> 4) ^ C::swz(rh))) << 4) + (byte0 & 15));
+  }
+  // (oh, ow) of the lane's lo pixel, advanced by 32 pixels per step with one carry per dimension
+  const int HW = p.H * p.W;
+  int st_oh, st_ow;
+  {
+    const unsigned pp = (unsigned)(P0 + kl) < (unsigned)p.M ? (unsigned)(P0 + kl) : 0u;
+    const int n = (int)(((unsigned long long)pp * p.mul_hw) >> p.sh_hw);
+    const unsigned rem = pp - (unsigned)n * (unsigned)HW;
+    st_oh = (int)(((unsigned long long)rem * p.mul_w) >> p.sh_w);
+    st_ow = (int)rem - st_oh * p.W;
+  }
+  const int d_r = 32 % HW, d_oh = d_r / p.W, d_ow = d_r - d_oh * p.W;
+
+  auto compute = [&](int stage, unsigned rot) {
+    const unsigned char* dyt = smem + RING_DY + stage * 4096;
+    // dy fragments (A operand): the step's own tile, rows 8 fq + q (+ 4), as in wgrad_kernel
+    const int row = 8 * fq + q4;
+    const int sw = C::swz(row);
+    u32x4 fa[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int byte = (wco * 32 + a * 16 + 4 * pq) * 2;
+      const unsigned char* a0 = dyt + row * 128 + ((((byte >> 4) ^ sw)) << 4) + (byte & 15);
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0)));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0 + 512)));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      fa[a] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+    }
+    // border flags of the lane's two pixels
+    int oh_h = st_oh, ow_h = st_ow + 4;
+    if (ow_h >= p.W) { ow_h -= p.W; ++oh_h; }
+    if (oh_h >= p.H) oh_h -= p.H;
+    bool hl_[R], hh_[R], wl_[3], wh_[3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      hl_[r] = (unsigned)(st_oh + r - p.pad_h) < (unsigned)p.H;
+      hh_[r] = (unsigned)(oh_h + r - p.pad_h) < (unsigned)p.H;
+    }
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      wl_[sx] = (unsigned)(st_ow + sx - 1) < (unsigned)p.W;
+      wh_[sx] = (unsigned)(ow_h + sx - 1) < (unsigned)p.W;
+    }
+    const unsigned zrow = (unsigned)RING_ZERO + (unsigned)(8 * (pq & 1));
+    // all tap addresses first (VALU only), then the fragment reads software-pipelined ONE TAP AHEAD of the MFMAs that
+    // consume them: with the reads of tap t issued right in front of its MFMAs a wave waited out the LDS latency nine
+    // times per step (the kernel ran at ~30 % MFMA-busy whatever its fill scheme)
+    unsigned al[NT], ah[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int r = t / 3, sx = t - r * 3;
+      al[t] = (hl_[r] && wl_[sx]) ? ((A_lo[t] + rot) & (RING_BYTES - 1)) : zrow;
+      ah[t] = (hh_[r] && wh_[sx]) ? ((A_hi[t] + rot) & (RING_BYTES - 1)) : zrow;
+    }
+    auto rd_tap = [&](int t, u32x4 (&fb)[2]) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        // column block b: +16 channels = +2 chunks = bit 1 of the chunk index, untouched by the swizzle's XOR pattern
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + (al[t] ^ (b * 32))));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + (ah[t] ^ (b * 32))));
+        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        fb[b] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+      }
+    };
+    u32x4 fbA[2], fbB[2];
+    rd_tap(0, fbA);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      u32x4 (&cur)[2] = (t & 1) ? fbB : fbA;
+      u32x4 (&nxt)[2] = (t & 1) ? fbA : fbB;
+      if (t + 1 < NT) rd_tap(t + 1, nxt);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                                 __builtin_bit_cast(bf16x8_t, cur[b]), acc[t][a][b], 0, 0, 0);
+    }
+    // next step: 32 pixels on
+    st_ow += d_ow;
+    const bool cw = st_ow >= p.W;
+    st_ow -= cw ? p.W : 0;
+    st_oh += d_oh + (cw ? 1 : 0);
+    if (st_oh >= p.H) st_oh -= p.H;
+  };
+
+  const int nsteps = s_end - s_begin;
+  if (nsteps > 0) {
+    // prologue: the window of the first step, [P0 - HLa, P0 + 32 + HLa), its dy tile, and the fill groups of the next
+    // RING_D - 1 steps; everything waited for once
+    for (int pc = wv; pc * 8 < 32 + 2 * p.HLa; pc += 4) x_piece(P0 - p.HLa + pc * 8);
+    dy_piece(0, s_begin);
+    for (int j = 1; j < RING_D && j < nsteps; ++j) dma_step(j, s_begin + j);
+    ring_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // (the zero row's ds_write is covered by the lgkmcnt wait hipcc puts before it)
+    unsigned rot = 0u;
+    for (int k = 0; k < nsteps; ++k) {
+      // fills RING_D steps ahead: dy stage (k + RING_D) & 3 was read in step k - 1 (every wave is past its barrier); the
+      // ring slots they overwrite hold pixels 256 rows back, behind this step's window (host: HL + HLa + 32 RING_D + 32 <= 256)
+      if (k + RING_D < nsteps) dma_step((k + RING_D) % RING_NDY, s_begin + k + RING_D);
+      compute(k % RING_NDY, rot);
+      rot = (rot + 4096u) & (RING_BYTES - 1);
+      // step k + 1's fills have landed: all but the groups of the steps after it (2 DMAs each) -- this wave's, then
+      // (barrier) everybody's; the LDS reads of this step are back, so its dy stage and ring rows may be overwritten
+      const int younger = (k + RING_D < nsteps ? k + RING_D : nsteps - 1) - (k + 1);
+      if (younger >= 2) ring_wait_vmcnt<4>();
+      else if (younger == 1) ring_wait_vmcnt<2>();
+      else ring_wait_vmcnt<0>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- slab store (identical layout to wgrad_kernel: [split][tap][co][ci])
+  float* base = p.slab + (((size_t)split * NT) * p.Cout + co0 + wco * 32 + fq * 4) * p.Cin + ci0 + wci * 32 + fr;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) base[((size_t)t * p.Cout + a * 16 + j) * p.Cin + b * 16] = acc[t][a][b][j];
+}
+
 // exact unsigned division by d for dividends < 2^31: q = (x * m) >> sh
 void magic_div(unsigned d, unsigned& m, unsigned& sh) {
   int l = 0;
@@ -374,6 +636,40 @@ int launch_wgrad(const ConvGeom& g, WgradParams& p, int nsplit, hipStream_t stre
   ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: %dx%d filter unsupported (1, 3 or 9 taps)", g.R, g.S);
 }
 
+int g_wgrad_ring = -1;   // ECGMM_WGRAD_RING: 0 = wgrad_kernel everywhere, 1 = ring kernel where it is faster (default), 2 = wherever applicable
+
+bool wgrad_ring_ok(int dtype, const ConvGeom& g) {
+  if (g_wgrad_ring < 0) {
+    const char* e = getenv("ECGMM_WGRAD_RING");
+    g_wgrad_ring = e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+  }
+  if (!g_wgrad_ring || dtype != ECGMM_BF16 || g.stride != 1 || g.S != 3 || g.pad_w != 1) return false;
+  if (!((g.R == 3 && g.pad_h == 1) || (g.R == 1 && g.pad_h == 0))) return false;
+  if (g.OH != g.H || g.OW != g.W || g.W < 4 || g.Cin % 64 || g.Cout % 64) return false;
+  const int HL = g.pad_h * g.W + 1, HLa = (HL + 7) / 8 * 8;
+  if (HL + HLa + 32 * RING_D + 32 > RING_ROWS) return false;
+  const double M = (double)g.N * g.H * g.W;
+  if (!(M * g.Cin * 2.0 < 2.0e9 && M * g.Cout * 2.0 < 2.0e9)) return false;
+  if (g_wgrad_ring == 2) return true;
+  // Same-call A/B at B = 256 (profiles/r02_wgrad_ring_ab.txt): +10 % on the 64-channel 3x3 layers and +3...6 % on the
+  // 1-D k = 3 layers; 5-8 % SLOWER on the 128-512-channel 3x3 layers, although it moves a fifth of the operand bytes,
+  // keeps fills three steps ahead and reads fragments a tap ahead -- those launches are bound by their 75 MB of fp32
+  // split-K slabs (write + re-read by the reduce kernel), not by the K loop.
+  return g.R == 1 || g.Cin == 64;
+}
+
+template <int NT>
+int launch_wgrad_ring(const WgradRingParams& p, dim3 grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_ring_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_ring_kernel<NT>), grid, dim3(256), RING_LDS, stream, p);
+  ECG_CHECK_LAUNCH("wgrad_ring_kernel");
+  return 0;
+}
+
 int pick_nsplit(const ConvGeom& g, int kp) {
   long M = (long)g.N * g.OH * g.OW;
   int tiles = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
@@ -386,6 +682,12 @@ int pick_nsplit(const ConvGeom& g, int kp) {
 }
 
 }  // namespace
+
+// Runtime switch (same-process A/B, tools/conv_bench.py --ring): 0 = every weight gradient on wgrad_kernel.
+extern "C" int ecgmm_conv_wgrad_ring_enable(int on) {
+  g_wgrad_ring = on < 0 ? 0 : on > 2 ? 2 : on;
+  return 0;
+}
 
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g) {
   int ns = pick_nsplit(g, dtype == ECGMM_BF16 ? 32 : 16);
@@ -416,7 +718,20 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
                  (double)dtype_size(dtype) * ((double)g.N * g.H * g.W * g.Cin + (double)M * g.Cout) +
                      4.0 * g.R * g.S * g.Cin * g.Cout,
                  stream);
-  int rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, stream) : launch_wgrad<float>(g, p, ns, stream);
+  int rc;
+  if (wgrad_ring_ok(dtype, g)) {
+    WgradRingParams q;
+    q.x = x; q.dy = dy; q.slab = (float*)workspace;
+    q.H = g.H; q.W = g.W; q.Cin = g.Cin; q.Cout = g.Cout; q.pad_h = g.pad_h; q.M = (int)M;
+    q.steps_per_split = p.steps_per_split;
+    q.HL = g.pad_h * g.W + 1;
+    q.HLa = (q.HL + 7) / 8 * 8;
+    q.mul_hw = p.mul_hw; q.sh_hw = p.sh_hw; q.mul_w = p.mul_w; q.sh_w = p.sh_w;
+    dim3 grid((g.Cout / 64) * (g.Cin / 64), ns);
+    rc = g.R == 3 ? launch_wgrad_ring<9>(q, grid, stream) : launch_wgrad_ring<3>(q, grid, stream);
+  } else {
+    rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, stream) : launch_wgrad<float>(g, p, ns, stream);
+  }
   ecg_prof_end(stream);
   ECG_TRY(rc);
   size_t per = (size_t)g.R * g.S * g.Cout * g.Cin;

@@ -49,10 +49,12 @@ def _conv_ref(x, w, b, stride, ph, pw):
 
 @pytest.fixture
 def halo_everywhere():
-    """conv_halo.hip for every shape it can serve (the default only picks it where it is the faster kernel)"""
+    """conv_halo.hip / wgrad_ring_kernel for every shape they can serve (the defaults only pick them where faster)"""
     L.lib().ecgmm_conv_halo_enable(2)
+    L.lib().ecgmm_conv_wgrad_ring_enable(2)
     yield
     L.lib().ecgmm_conv_halo_enable(1)
+    L.lib().ecgmm_conv_wgrad_ring_enable(1)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)

@@ -14,6 +14,7 @@ ap.add_argument("--layers", default="")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--no-stats", action="store_true", help="forward without the fused BatchNorm partial sums")
 ap.add_argument("--lib", default="", help="A/B: path of another build of libecgmm_hip.so")
+ap.add_argument("--ring", type=int, default=-1, help="wgrad_ring_kernel: 0 off, 1 on (default)")
 ap.add_argument("--halo", type=int, default=-1, help="conv_halo.hip: 0 never, 1 where faster (default), 2 wherever applicable")
 a = ap.parse_args()
 if a.lib:
@@ -31,6 +32,8 @@ SHAPES = [  # name, H, W, Cin, Cout, R, S, stride, ph, pw
 lib = L.lib()
 if a.halo >= 0:
     lib.ecgmm_conv_halo_enable(a.halo)
+if a.ring >= 0:
+    lib.ecgmm_conv_wgrad_ring_enable(a.ring)
 dev = torch.device("cuda:0")
 sel = set(a.layers.split(",")) if a.layers else None
 tot = {}
