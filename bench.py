@@ -323,7 +323,7 @@ def main():
         if args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and os.path.exists(tpath):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"], 1)
         ach = ig_fl / (ig_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "igemm_kernel<%s> (conv fwd + dgrad)" % ("bf16" if args.dtype == "bf16" else "f32"), "achieved": round(ach, 2), "peak": peak,
+        return {"bound": "mfma", "kernel": ("igemm_kernel<bf16> + conv_halo_kernel (conv fwd + dgrad)" if args.dtype == "bf16" else "igemm_kernel<f32> (conv fwd + dgrad)"), "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(ig_by / max(ig_n, 1), 1), "launches": ig_n,
                 "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4), "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),

@@ -581,6 +581,7 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
     const double esz = (double)dtype_size(dtype);
     double bytes = esz * ((double)g.N * p.Hs * p.Ws * p.Cs + (double)M * p.Cd * (addend ? 2.0 : 1.0) +
                           (double)g.R * g.S * g.Cin * g.Cout);
+    if (epi && epi->red_y) bytes += esz * (double)M * p.Cd * (epi->red_mask ? 2.0 : 1.0);  // fused BN-backward reduction operands
     ecg_prof_begin(dtype == ECGMM_F32 ? (mode == 0 ? ECG_PROF_IGEMM_F32_FWD : ECG_PROF_IGEMM_F32_DGRAD)
                                       : (mode == 0 ? ECG_PROF_IGEMM_FWD : ECG_PROF_IGEMM_DGRAD),
                    conv_flops(g), bytes, stream);
