@@ -128,6 +128,12 @@ int ecgmm_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const 
                            int W, int C, void* stream) {
   return ecg_maxpool_relu_bwd(dtype, dp, pooled, idx, dz, N, H, W, C, S_(stream));
 }
+int ecgmm_pool_bn_bwd(int dtype, const void* dp, const void* pooled, const uint8_t* idx, const void* y, const float* coef,
+                      const float* gamma, float* dgamma, float* dbeta, void* dy, float* dbias, int N, int H, int W, int C,
+                      void* scratch, void* stream) {
+  return ecg_pool_bn_bwd(dtype, dp, pooled, idx, y, coef, gamma, dgamma, dbeta, dy, dbias, N, H, W, C, (float*)scratch,
+                         S_(stream));
+}
 int ecgmm_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, void* stream) {
   return ecg_avgpool(dtype, x, out, N, R, C, coef, S_(stream));
 }

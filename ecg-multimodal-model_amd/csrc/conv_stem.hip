@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     const int i = tid + 256 * k;
     const int pix = i / CH, chunk = i % CH;
     const int oh = oh0 + pix / TW, ow = ow0 + pix % TW;
-    dyoff[k] = (oh < p.OH) & (ow < p.OW) ? (unsigned)(((oh * p.OW + ow) * STEM_CO) * (int)sizeof(T) + chunk * 16) : 0xFFFFFFFFu;
+    dyoff[k] = ((oh < p.OH) & (ow < p.OW)) ? (unsigned)(((oh * p.OW + ow) * STEM_CO) * (int)sizeof(T) + chunk * 16) : 0xFFFFFFFFu;
   }
   auto fetch = [&](int n) {
     const size_t dimg = (size_t)p.OH * p.OW * STEM_CO;

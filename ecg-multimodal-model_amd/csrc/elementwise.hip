@@ -531,6 +531,184 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_relu_bwd_kernel(const T* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem backward without the full-resolution intermediate: BatchNorm-backward reduction over the POOLED tensors, and
+// max-pool backward + BatchNorm-backward apply in one pass.
+//   The max-pool routes each window's gradient to one input position, and there bn(y) equals the pooled value p (> 0;
+//   a window with p = 0 passes nothing through the ReLU).  So with g = dp * [p > 0] summed over WINDOWS:
+//     sum_pixels dz         = sum g
+//     sum_pixels dz (y - m) = sum g * (p - beta) / (gamma * invstd)        (p = gamma * xhat + beta at the arg-max)
+//   which reads 2 pooled tensors (1/4 size) instead of dz and y at full resolution, and never needs dz in memory.
+//   (bf16: p is stored rounded, so xhat recovered from it carries p's rounding, 2^-9 relative, instead of y's.)
+//   A channel with gamma * invstd == 0 has no recoverable xhat: its dgamma row is 0 (torch would give sum dz * xhat;
+//   such a channel outputs the constant beta).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BWD_THREADS) void pool_bwd_reduce_kernel(const T* __restrict__ dp,
+                                                                      const T* __restrict__ pooled,
+                                                                      const float* __restrict__ coef,
+                                                                      float* __restrict__ partial, long MP, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float shm_dyn[];
+  float(*shm)[2 * VEC + 1] = reinterpret_cast<float(*)[2 * VEC + 1]>(shm_dyn);
+  const int cpr = C / VEC, rpi = BWD_THREADS / cpr;
+  const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
+  const int c0 = chunk * VEC;
+  float beta[VEC], rsc[VEC], a1[VEC], a2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float sc = coef[c0 + j];                               // gamma * invstd
+    beta[j] = coef[C + c0 + j] + coef[2 * C + c0 + j] * sc;      // shift + mean * scale
+    rsc[j] = sc != 0.f ? 1.f / sc : 0.f;
+    a1[j] = a2[j] = 0.f;
+  }
+  for (long r = (long)blockIdx.x * rpi + r0; r < MP; r += (long)gridDim.x * rpi) {
+    float d[VEC], v[VEC];
+    unpack16<T>(ld16(dp + r * C + c0), d);
+    unpack16<T>(ld16(pooled + r * C + c0), v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float g = v[j] > 0.f ? d[j] : 0.f;
+      a1[j] += g;
+      a2[j] += g * (v[j] - beta[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    shm[threadIdx.x][j] = a1[j];
+    shm[threadIdx.x][VEC + j] = a2[j] * rsc[j];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += BWD_THREADS) {
+    int which = o / C, c = o % C;
+    int ck = c / VEC, j = c % VEC;
+    float sum = 0.f;
+    for (int k = 0; k < rpi; ++k) sum += shm[k * cpr + ck][which * VEC + j];
+    partial[(size_t)blockIdx.x * 2 * C + o] = sum;
+  }
+}
+
+// dy = k1 * (dz - k2 - xhat * k3) with dz gathered on the fly from the pooled gradient (same 2x2-pixel-block scheme and
+// tap table as maxpool_relu_bwd_kernel above); optional partial rows of sum(dy as stored) for a conv bias gradient.
+// Written as dy = k1 * dz + (bn * y + an) with an = k1 * (k3 * invstd * mean - k2), bn = -k1 * k3 * invstd: 3 constants
+// per channel.  512-thread blocks: the four windows + four pixels in flight per thread need ~150 VGPRs.
+constexpr int POOL_THREADS = 512;
+template <typename T>
+__global__ __launch_bounds__(POOL_THREADS) void pool_bn_bwd_apply_kernel(const T* __restrict__ dp,
+                                                                         const T* __restrict__ pooled,
+                                                                         const unsigned char* __restrict__ idx,
+                                                                         const T* __restrict__ y,
+                                                                         const float* __restrict__ coef,
+                                                                         const float* __restrict__ bcoef,
+                                                                         T* __restrict__ dy, float* __restrict__ partial,
+                                                                         int N, int H, int W, int C, int OH, int OW) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float shm_dyn[];
+  float(*shm)[VEC + 1] = reinterpret_cast<float(*)[VEC + 1]>(shm_dyn);
+  const int cpr = C / VEC;
+  const int chunk = threadIdx.x % cpr;
+  const int c0 = chunk * VEC;
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const long nblk = (long)N * H2 * W2;
+  const int bpi = POOL_THREADS / cpr;
+  float k1[VEC], an[VEC], bn[VEC], a1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float mean = coef[2 * C + c0 + j], inv = coef[3 * C + c0 + j];
+    k1[j] = bcoef[c0 + j];
+    bn[j] = -k1[j] * bcoef[2 * C + c0 + j] * inv;
+    an[j] = -k1[j] * bcoef[C + c0 + j] - bn[j] * mean;
+    a1[j] = 0.f;
+  }
+  for (long blk = (long)blockIdx.x * bpi + threadIdx.x / cpr; blk < nblk; blk += (long)gridDim.x * bpi) {
+    int m = (int)(blk % W2);
+    long t = blk / W2;
+    int k = (int)(t % H2), n = (int)(t / H2);
+    const int h0 = 2 * k, w0 = 2 * m;
+    const bool okw = w0 + 1 < W, okh = h0 + 1 < H;
+    const size_t base = (((size_t)n * H + h0) * W + w0) * C + c0;
+    // all loads up front: 4 windows x (dp, pooled, arg-max bytes) + 4 pixels of y
+    u32x4 rd[4], rp[4], ry[4];
+    unsigned pk[4][2];
+    bool wok[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int q = a * 2 + b;
+        wok[q] = k + a < OH && m + b < OW;
+        const size_t o = (((size_t)n * OH + (wok[q] ? k + a : k)) * OW + (wok[q] ? m + b : m)) * C + c0;
+        rd[q] = ld16(dp + o);
+        rp[q] = ld16(pooled + o);
+        if constexpr (VEC == 8) {
+          const uint2 t2 = *reinterpret_cast<const uint2*>(idx + o);
+          pk[q][0] = t2.x;
+          pk[q][1] = t2.y;
+        } else {
+          pk[q][0] = *reinterpret_cast<const unsigned*>(idx + o);
+          pk[q][1] = 0;
+        }
+      }
+    ry[0] = ld16(y + base);
+    ry[1] = ld16(y + (okw ? base + C : base));
+    ry[2] = ld16(y + (okh ? base + (size_t)W * C : base));
+    ry[3] = ld16(y + (okh ? base + (size_t)W * C : base) + (okw ? C : 0));
+    float d[4][VEC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float pv[VEC];
+      unpack16<T>(rd[q], d[q]);
+      unpack16<T>(rp[q], pv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[q][j] = (wok[q] && pv[j] > 0.f) ? d[q][j] : 0.f;
+    }
+    auto g = [&](int q, int tap, int j) -> float {
+      const int code = (int)((pk[q][j >> 2] >> (8 * (j & 3))) & 0xffu);
+      return code == tap ? d[q][j] : 0.f;
+    };
+    float o[4][VEC];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float v[VEC];
+      unpack16<T>(ry[px], v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z;
+        if (px == 0) z = g(0, 4, j);
+        else if (px == 1) z = g(0, 5, j) + g(1, 3, j);
+        else if (px == 2) z = g(0, 7, j) + g(2, 1, j);
+        else z = ((g(0, 8, j) + g(1, 6, j)) + g(2, 2, j)) + g(3, 0, j);
+        o[px][j] = k1[j] * z + (bn[j] * v[j] + an[j]);
+      }
+    }
+    const u32x4 p00 = pack16<T>(o[0]), p01 = pack16<T>(o[1]), p10 = pack16<T>(o[2]), p11 = pack16<T>(o[3]);
+    st16(dy + base, p00);
+    if (okw) st16(dy + base + C, p01);
+    if (okh) {
+      st16(dy + base + (size_t)W * C, p10);
+      if (okw) st16(dy + base + (size_t)W * C + C, p11);
+    }
+    if (partial) {  // sum what was actually stored
+      float b0[VEC], b1[VEC], b2[VEC], b3[VEC];
+      unpack16<T>(p00, b0); unpack16<T>(p01, b1); unpack16<T>(p10, b2); unpack16<T>(p11, b3);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        a1[j] += b0[j] + (okw ? b1[j] : 0.f) + (okh ? b2[j] : 0.f) + (okh && okw ? b3[j] : 0.f);
+    }
+  }
+  if (partial) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) shm[threadIdx.x][j] = a1[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += POOL_THREADS) {
+      int ck = c / VEC, j = c % VEC;
+      float sum = 0.f;
+      for (int k = 0; k < bpi; ++k) sum += shm[k * cpr + ck][j];
+      partial[(size_t)blockIdx.x * C + c] = sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // global average pool over the rows of each sample: [N][R][C] T -> [N][C] f32; and its broadcast
 // ------------------------------------------------------------------------------------------------
 // One block per sample; thread = (16-B channel chunk, row slice); LDS fold over the slices.
@@ -879,6 +1057,57 @@ int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void
   p.bcoef = bcoef; p.dy = dy;
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");
+  return 0;
+}
+
+// Stem backward: [max-pool 3/2/1 <- ReLU <- BatchNorm] in two passes over the pooled tensors + one over y (kernels above).
+// scratch as ecg_bn_bwd_scratch(dtype, N*H*W, C).  dbias (nullable): sum of dy (the stem conv's bias gradient).
+template <typename T>
+static void pool_bwd_launch(const void* dp, const void* pooled, const unsigned char* idx, const void* y, const float* coef,
+                            const float* gamma, float* dgamma, float* dbeta, void* dy, float* dbias, int N, int H, int W,
+                            int C, int OH, int OW, float* scratch, int rows, hipStream_t stream) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr size_t lds2 = (size_t)BWD_THREADS * (2 * VEC + 1) * sizeof(float), ldsp = (size_t)POOL_THREADS * (VEC + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pool_bwd_reduce_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    attr_set = true;
+  }
+  const long MP = (long)N * OH * OW, M = (long)N * H * W;
+  float* partial = scratch;
+  float* bcoef = scratch + (size_t)(rows + ECG_TAIL_ROWS) * 2 * C;
+  const int rpi = BWD_THREADS / (C / VEC);
+  int g1 = ew_grid(MP, rpi * 8);
+  g1 = g1 > rows ? rows : g1;
+  hipLaunchKernelGGL(pool_bwd_reduce_kernel<T>, dim3(g1), dim3(BWD_THREADS), lds2, stream, (const T*)dp, (const T*)pooled,
+                     coef, partial, MP, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, (const float*)partial, g1, C,
+                     (double)M, gamma, coef, dgamma, dbeta, bcoef, 1);
+  const long nblk = (long)N * ((H + 1) / 2) * ((W + 1) / 2);
+  int g2 = ew_grid(nblk, POOL_THREADS / (C / VEC));
+  if (dbias && g2 > rows) g2 = rows;   // one partial row per block
+  hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<T>, dim3(g2), dim3(POOL_THREADS), dbias ? ldsp : 0, stream, (const T*)dp,
+                     (const T*)pooled, idx, (const T*)y, coef, (const float*)bcoef, (T*)dy, dbias ? partial : nullptr, N, H, W,
+                     C, OH, OW);
+  if (dbias) hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, (const float*)partial, g2, C, dbias, 0);
+}
+
+// ECGMM_STEM_FUSE=0: the plans fall back to max-pool backward + full BatchNorm backward as separate passes (A/B switch)
+bool ecg_stem_fuse_on() {
+  static const bool on = [] { const char* e = getenv("ECGMM_STEM_FUSE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+int ecg_pool_bn_bwd(int dtype, const void* dp, const void* pooled, const unsigned char* idx, const void* y,
+                    const float* coef, const float* gamma, float* dgamma, float* dbeta, void* dy, float* dbias, int N,
+                    int H, int W, int C, float* scratch, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "pool_bn_bwd: C=%d unsupported", C);
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int rows = bn_bwd_rows(dtype, (long)N * H * W, C);
+  DISPATCH_T(dtype, (pool_bwd_launch<bf16_t>(dp, pooled, idx, y, coef, gamma, dgamma, dbeta, dy, dbias, N, H, W, C, OH, OW, scratch, rows, stream)),
+             (pool_bwd_launch<float>(dp, pooled, idx, y, coef, gamma, dgamma, dbeta, dy, dbias, N, H, W, C, OH, OW, scratch, rows, stream)),
+             "pool_bn_bwd");
+  ECG_CHECK_LAUNCH("pool_bn_bwd");
   return 0;
 }
 

@@ -60,6 +60,10 @@ int ecg_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, u
                        int C, hipStream_t stream);
 int ecg_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const unsigned char* idx, void* dz, int N,
                          int H, int W, int C, hipStream_t stream);
+int ecg_pool_bn_bwd(int dtype, const void* dp, const void* pooled, const unsigned char* idx, const void* y,
+                    const float* coef, const float* gamma, float* dgamma, float* dbeta, void* dy, float* dbias, int N,
+                    int H, int W, int C, float* scratch, hipStream_t stream);
+bool ecg_stem_fuse_on();
 int ecg_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, hipStream_t stream);
 int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, hipStream_t stream);
 int ecg_se_gate_grad(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, float* dg,

@@ -439,9 +439,14 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       }
     } else if (st == 9) {
       const void* dp0 = q.X[8 & 1];
-      ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, r.H1, r.W1, 64, s));
-      ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 1), G(grads, 1),
-                         G(grads, 2), q.big1, nullptr, nullptr, (long)N * r.H1 * r.W1, 64, q.bn_scratch, s));
+      if (ecg_stem_fuse_on()) {
+        ECG_TRY(ecg_pool_bn_bwd(dt, dp0, w.p0, w.idx0, w.y0, w.coef0, P(params, 1), G(grads, 1), G(grads, 2), q.big1,
+                                nullptr, N, r.H1, r.W1, 64, q.bn_scratch, s));
+      } else {
+        ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, r.H1, r.W1, 64, s));
+        ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 1), G(grads, 1),
+                           G(grads, 2), q.big1, nullptr, nullptr, (long)N * r.H1 * r.W1, 64, q.bn_scratch, s));
+      }
       if (G(grads, 0)) {
         // the last kernel of the backward stays on the caller's stream: nothing is left there to overlap it with, it
         // overlaps the side stream's remaining wgrads instead, and the join below then waits for an event that has

@@ -377,9 +377,14 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
       }
     } else if (st == 4) {
       const void* dp0 = q.X[3 & 1];
-      ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, 1, r.L1, 64, s));
-      ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 2), G(grads, 2),
-                         G(grads, 3), q.big1, nullptr, G(grads, 1), (long)N * r.L1, 64, q.bn_scratch, s));
+      if (ecg_stem_fuse_on()) {
+        ECG_TRY(ecg_pool_bn_bwd(dt, dp0, w.p0, w.idx0, w.y0, w.coef0, P(params, 2), G(grads, 2), G(grads, 3), q.big1,
+                                G(grads, 1), N, 1, r.L1, 64, q.bn_scratch, s));
+      } else {
+        ECG_TRY(ecg_maxpool_relu_bwd(dt, dp0, w.p0, w.idx0, q.big0, N, 1, r.L1, 64, s));
+        ECG_TRY(ecg_bn_bwd(dt, q.big0, nullptr, nullptr, nullptr, 1, w.y0, w.coef0, P(params, 2), G(grads, 2),
+                           G(grads, 3), q.big1, nullptr, G(grads, 1), (long)N * r.L1, 64, q.bn_scratch, s));
+      }
       if (G(grads, 0))  // last kernel: stays on the caller's stream (own slab buffer), see plan_resnet18.hip
         ECG_TRY(ecg_stem_wgrad(dt, signal, q.big1, G(grads, 0), 0, q.stem_ws, q.stem_bytes, N, cin, 1, r.d.L, 1, s));
     } else {

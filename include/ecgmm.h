@@ -221,6 +221,13 @@ int ecgmm_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out,
                          int C, void* stream);
 int ecgmm_maxpool_relu_bwd(int dtype, const void* dp, const void* pooled, const uint8_t* idx, void* dz, int N, int H,
                            int W, int C, void* stream);
+/* Backward of [BatchNorm -> ReLU -> MaxPool(3,2,1)] in one call, without the full-resolution pooled-gradient tensor: the
+ * BatchNorm reduction runs over the pooled tensors (dp, pooled), the apply pass gathers the max-pool backward on the fly.
+ * Same results as ecgmm_maxpool_relu_bwd + ecgmm_bn_bwd up to the rounding of `pooled` (header of the kernels in
+ * csrc/elementwise.hip).  scratch: ecgmm_bn_bwd_scratch(dtype, N*H*W, C) bytes.  dbias nullable (sum of dy). */
+int ecgmm_pool_bn_bwd(int dtype, const void* dp, const void* pooled, const uint8_t* idx, const void* y, const float* coef,
+                      const float* gamma, float* dgamma, float* dbeta, void* dy, float* dbias, int N, int H, int W, int C,
+                      void* scratch, void* stream);
 /* AdaptiveAvgPool(1) (+ optional per-channel affine of the mean) and its broadcast backward */
 int ecgmm_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const float* coef, void* stream);
 int ecgmm_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, void* stream);

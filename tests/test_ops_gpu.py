@@ -381,6 +381,71 @@ def test_bnrelu_maxpool_fwd_bwd(dt, shape):
         assert rel_err(dz, ref) < 0.05
 
 
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("shape", [(2, 64, 12, 10), (3, 64, 1, 41), (2, 64, 9, 7), (4, 64, 28, 28)])
+def test_stem_backward_over_pooled_tensors_matches_the_two_pass_form(dt, shape):
+    """ecgmm_pool_bn_bwd == ecgmm_maxpool_relu_bwd + ecgmm_bn_bwd == torch autograd of maxpool(relu(bn(y)))
+    (resnet18 stem bn1/relu/maxpool; ResNet1D_SE.initial[1:4], multimodal_paper_modal_balance.py:100-104)"""
+    N, Cn, H, W = shape
+    lib = L.lib()
+    M = N * H * W
+    y = fill.hash_tensor(shape, 51, 2.0)
+    if dt == L.BF16:
+        y = bf16_round(y)
+    gam = 1 + 0.3 * fill.hash_tensor((Cn,), 52)
+    bet = 0.2 * fill.hash_tensor((Cn,), 53)
+    yr, gr, br = y.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    z = F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5))
+    p_ref = F.max_pool1d(z[:, :, 0], 3, 2, 1)[:, :, None] if H == 1 else F.max_pool2d(z, 3, 2, 1)
+    dp = fill.hash_tensor(tuple(p_ref.shape), 54)
+    if dt == L.BF16:
+        dp = bf16_round(dp)
+    p_ref.backward(dp)
+
+    yg = to_nhwc(y, dt)
+    rows = lib.ecgmm_col_stats_rows(dt, M, Cn)
+    partial = torch.empty(rows, 2, Cn, device=DEV)
+    L.check(lib.ecgmm_col_stats(dt, ptr(yg), M, Cn, ptr(partial), stream()))
+    coef = torch.empty(4, Cn, device=DEV)
+    rmg, rvg, nbt = dev(torch.zeros(Cn)), dev(torch.ones(Cn)), torch.zeros((), dtype=torch.int64, device=DEV)
+    gg, bg = dev(gam), dev(bet)
+    L.check(lib.ecgmm_bn_finalize(ptr(partial), rows, Cn, float(M), ptr(gg), ptr(bg), ptr(rmg), ptr(rvg), ptr(nbt),
+                                  0.1, 1e-5, ptr(coef), stream()))
+    OH, OW = p_ref.shape[2], p_ref.shape[3]
+    pg = torch.empty(N * OH * OW * Cn, device=DEV, dtype=TDT[dt])
+    idx = torch.empty(N * OH * OW * Cn, device=DEV, dtype=torch.uint8)
+    L.check(lib.ecgmm_bnrelu_maxpool(dt, ptr(yg), ptr(coef), ptr(pg), ptr(idx), N, H, W, Cn, stream()))
+    dpg = to_nhwc(dp, dt)
+    scratch = torch.empty(lib.ecgmm_bn_bwd_scratch(dt, M, Cn), device=DEV, dtype=torch.uint8)
+
+    def two_pass():
+        dzg, dyg = torch.empty_like(yg), torch.empty_like(yg)
+        dgam, dbet, dbias = (torch.zeros(Cn, device=DEV) for _ in range(3))
+        L.check(lib.ecgmm_maxpool_relu_bwd(dt, ptr(dpg), ptr(pg), ptr(idx), ptr(dzg), N, H, W, Cn, stream()))
+        L.check(lib.ecgmm_bn_bwd(dt, ptr(dzg), None, None, None, 1, ptr(yg), ptr(coef), ptr(gg), ptr(dgam), ptr(dbet),
+                                 ptr(dyg), None, ptr(dbias), M, Cn, ptr(scratch), stream()))
+        return from_nhwc(dyg, dt, shape), dgam.cpu(), dbet.cpu(), dbias.cpu()
+
+    def pooled_form():
+        dyg = torch.empty_like(yg)
+        dgam, dbet, dbias = (torch.zeros(Cn, device=DEV) for _ in range(3))
+        L.check(lib.ecgmm_pool_bn_bwd(dt, ptr(dpg), ptr(pg), ptr(idx), ptr(yg), ptr(coef), ptr(gg), ptr(dgam), ptr(dbet),
+                                      ptr(dyg), ptr(dbias), N, H, W, Cn, ptr(scratch), stream()))
+        return from_nhwc(dyg, dt, shape), dgam.cpu(), dbet.cpu(), dbias.cpu()
+
+    a, b = two_pass(), pooled_form()
+    tol = 2e-5 if dt == L.F32 else 1.5e-2
+    assert rel_err(b[0], a[0]) < tol and rel_err(b[1], a[1]) < tol and rel_err(b[2], a[2]) < tol
+    assert b[3].abs().max().item() < (1e-3 if dt == L.F32 else 0.5)  # analytically zero
+    gtol = 2e-4 if dt == L.F32 else 6e-2   # bf16: torch pools the unrounded activations, ties route differently
+    assert rel_err(b[0], yr.grad) < gtol and rel_err(b[1], gr.grad) < gtol and rel_err(b[2], br.grad) < gtol
+    # no dbias, no parameter gradients (frozen BatchNorm parameters): same dy
+    dyg = torch.empty_like(yg)
+    L.check(lib.ecgmm_pool_bn_bwd(dt, ptr(dpg), ptr(pg), ptr(idx), ptr(yg), ptr(coef), ptr(gg), None, None, ptr(dyg),
+                                  None, N, H, W, Cn, ptr(scratch), stream()))
+    assert torch.equal(from_nhwc(dyg, dt, shape), b[0])
+
+
 def test_avgpool_bcast_and_se_gate_grad():
     lib = L.lib()
     N, R, Cn = 3, 37, 128

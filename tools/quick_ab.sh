@@ -1,9 +1,10 @@
-# tests + two bench lines (no prof, no cpu baseline)
+# same-call A/B of one environment switch: tools/quick_ab.sh VAR  (bench lines with VAR=0 / VAR=1, twice each)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/quick; mkdir -p $O
-python3 -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py tests/test_fullsize_gpu.py tests/test_parallel_gpu.py -x -q > $O/test.log 2>&1 || { tail -30 $O/test.log; exit 1; }
-tail -2 $O/test.log
+V=${1:-ECGMM_STEM_FUSE}
+A=${2:-}
 for i in 1 2; do
-python3 bench.py --no-cpu-baseline --no-prof --steps 40 --warmup 10 > $O/plain_$i.json 2>/dev/null || exit 1
+  for x in 0 1; do
+    echo "== $V=$x" >> gpurun_out/ab.txt
+    env $V=$x python3 bench.py --no-cpu-baseline --no-prof $A 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['step_ms_hipevent'])" >> gpurun_out/ab.txt || exit 1
+  done
 done
-for f in $O/*.json; do python3 -c "import json,sys; d=json.load(open('$f')); print('$f', d['ms_per_step'])"; done
