@@ -70,16 +70,22 @@ template <> struct WgCfg<float> {
   static __device__ __forceinline__ int swz(int row) { return (row & 1) << 2; }
 };
 
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+// GROUPS = 2: a 512-thread workgroup is two 4-wave groups, each running the K loop below over its own half of the
+// workgroup's pixel slice with its own LDS stages; at the end group 1 hands its accumulators to group 0 through LDS
+// and ONE partial tile goes to the slab.  Same waves per CU as two 256-thread workgroups, half the split count: half the
+// fp32 slab bytes written here and re-read by the reduce kernel (75 MB -> 37 MB per 3x3 launch at batch 256).
+template <typename T, int NT, int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
   using C = WgCfg<T>;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int TILE_BYTES = C::KP * C::RB;  // 4096
   constexpr int STAGE_BYTES = (1 + NT) * TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][1 + NT tiles]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
+  unsigned char* const smem_g = smem + grp * 2 * STAGE_BYTES;
   const int wco = wave & 1, wci = wave >> 1;
   const int ci_tiles = (p.Cin + 63) / 64;
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest).  All (co, ci)
@@ -98,8 +104,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const T* __restrict__ dy = (const T*)p.dy;
 
   const int total_steps = (p.M + C::KP - 1) / C::KP;
-  const int s_begin = split * p.steps_per_split;
-  const int s_end = min(total_steps, s_begin + p.steps_per_split);
+  const int wg_begin = split * p.steps_per_split;
+  const int wg_end = min(total_steps, wg_begin + p.steps_per_split);
+  const int wg_len = max(wg_end - wg_begin, 0);
+  const int iters = GROUPS == 1 ? wg_len : (wg_len + 1) / 2;       // group 0's step count (>= group 1's)
+  const int s_begin = wg_begin + grp * iters;
+  const int s_end = GROUPS == 1 ? wg_end : min(wg_end, s_begin + iters);
+  const int my_len = max(s_end - s_begin, 0);
 
   f32x4 acc[NT][2][2];
 #pragma unroll
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   }
   const int lane_x = (int)(x_lane != OOB), lane_dy = (int)(dy_lane != OOB);
   auto dma = [&](int stage, int step) {
-    unsigned char* base = smem + stage * STAGE_BYTES + wv * 1024;
+    unsigned char* base = smem_g + stage * STAGE_BYTES + wv * 1024;
     const int pok = (int)(step * C::KP + drow < p.M);
     wg_dma16(rs_dy, base, (pok & lane_dy) ? st_dy : OOB);
     const int hb = __mul24(st_oh, p.stride) - p.pad_h, wb = __mul24(st_ow, p.stride) - p.pad_w;
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
   const int fr = lane & 15, fq = lane >> 4;
   auto compute = [&](int stage) {
-    const unsigned char* st = smem + stage * STAGE_BYTES;
+    const unsigned char* st = smem_g + stage * STAGE_BYTES;
     if constexpr (sizeof(T) == 2) {
       // transposing reads: lane 4q+p of a 16-lane group addresses row (kb+q), columns 4p..4p+3;
       // lane i receives column i of those 4 rows.  Group fq takes k rows 8fq..8fq+7.
@@ -247,18 +258,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   unsigned long long sA = 0, sB = 0, sC = 0, t0, t1, t2, t3, tk0, tk1;
   ECG_WSTAMP_AT(tk0);
 #endif
-  if (s_begin < s_end) {
-    dma(0, s_begin);
+  if (iters > 0) {   // (every wave of the workgroup takes the same `iters` trips: the barriers below are workgroup-wide)
+    if (my_len > 0) dma(0, s_begin);
     __syncthreads();  // drains vmcnt: stage 0 has landed for every wave
-    for (int step = s_begin, k = 0; step < s_end; ++step, ++k) {
+    for (int k = 0; k < iters; ++k) {
 #ifdef ECG_STAMP
       ECG_WSTAMP_AT(t0);
 #endif
-      if (step + 1 < s_end) dma((k + 1) & 1, step + 1);  // buffer last read in iteration k-1, fenced by its barrier
+      if (k + 1 < my_len) dma((k + 1) & 1, s_begin + k + 1);  // buffer last read in iteration k-1, fenced by its barrier
 #ifdef ECG_STAMP
       ECG_WSTAMP_AT(t1);
 #endif
-      compute(k & 1);
+      if (GROUPS == 1 || k < my_len) compute(k & 1);
 #ifdef ECG_STAMP
       ECG_WSTAMP_AT(t2);
 #endif
@@ -280,6 +291,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     atomicAdd(&g_wstamp[7], (unsigned long long)(s_end - s_begin));
   }
 #endif
+
+  if constexpr (GROUPS == 2) {
+    // group 1 -> LDS -> group 0 (register r of thread t at float [r * 256 + t]: every access a contiguous 1-KiB row).
+    // The K loop's last barrier has retired every fragment read and every DMA, so the stages can be overwritten.
+    float* red = reinterpret_cast<float*>(smem) + (tid & 255);
+    if (grp == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(((t * 2 + a) * 2 + b) * 4 + j) * 256] = acc[t][a][b][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[t][a][b][j] += red[(((t * 2 + a) * 2 + b) * 4 + j) * 256];
+  }
 
   // ---- slab store: D[row = co][col = ci]; lane: ci = fr, co = fq*4 + j
   const int RS = NT;
@@ -612,27 +649,43 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int GROUPS>
 int launch_wgrad_nt(WgradParams& p, dim3 grid, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(1 + NT) * 4096;
+  size_t lds = (size_t)GROUPS * 2 * (1 + NT) * 4096;
+  if (GROUPS == 2 && lds < (size_t)NT * 16 * 1024) lds = (size_t)NT * 16 * 1024;   // the hand-over buffer: NT*16 floats x 256 threads
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, NT, GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<T, NT>), grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<T, NT, GROUPS>), grid, dim3(256 * GROUPS), lds, stream, p);
   ECG_CHECK_LAUNCH("wgrad_kernel");
   return 0;
 }
 
+// two 4-wave groups per workgroup (see wgrad_kernel): bf16 filters with 3 or 9 taps, where the slabs are the larger part of
+// the launch's traffic.  ECGMM_WGRAD_GROUPS=1 keeps 256-thread workgroups (A/B switch).
+int g_wgrad_groups = -1;
+int wgrad_groups(int dtype, const ConvGeom& g) {
+  if (g_wgrad_groups < 0) {
+    const char* e = getenv("ECGMM_WGRAD_GROUPS");
+    g_wgrad_groups = e && e[0] == '1' ? 1 : 2;
+  }
+  return dtype == ECGMM_BF16 && g.R * g.S >= 3 ? g_wgrad_groups : 1;
+}
+
 template <typename T>
-int launch_wgrad(const ConvGeom& g, WgradParams& p, int nsplit, hipStream_t stream) {
+int launch_wgrad(const ConvGeom& g, WgradParams& p, int nsplit, int groups, hipStream_t stream) {
   const int RS = g.R * g.S;
   dim3 grid(ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64), nsplit);
   if (g.S != 1 && g.S != 3) ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: filter width %d unsupported (1 or 3)", g.S);
-  if (RS == 1) return launch_wgrad_nt<T, 1>(p, grid, stream);
-  if (RS == 3) return launch_wgrad_nt<T, 3>(p, grid, stream);
-  if (RS == 9) return launch_wgrad_nt<T, 9>(p, grid, stream);
+  if constexpr (sizeof(T) == 2) {
+    if (groups == 2 && RS == 3) return launch_wgrad_nt<T, 3, 2>(p, grid, stream);
+    if (groups == 2 && RS == 9) return launch_wgrad_nt<T, 9, 2>(p, grid, stream);
+  }
+  if (RS == 1) return launch_wgrad_nt<T, 1, 1>(p, grid, stream);
+  if (RS == 3) return launch_wgrad_nt<T, 3, 1>(p, grid, stream);
+  if (RS == 9) return launch_wgrad_nt<T, 9, 1>(p, grid, stream);
   ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: %dx%d filter unsupported (1, 3 or 9 taps)", g.R, g.S);
 }
 
@@ -670,11 +723,11 @@ int launch_wgrad_ring(const WgradRingParams& p, dim3 grid, hipStream_t stream) {
   return 0;
 }
 
-int pick_nsplit(const ConvGeom& g, int kp) {
+int pick_nsplit(const ConvGeom& g, int kp, int groups) {
   long M = (long)g.N * g.OH * g.OW;
   int tiles = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
   int steps = ceil_div(M, kp);
-  int want = ceil_div(512, tiles);  // one resident round: 2 workgroups per CU (register-limited)
+  int want = ceil_div(512 / groups, tiles);  // one resident round: 8 waves per CU (register-limited)
   int ns = want < 1 ? 1 : want;
   if (ns > steps) ns = steps;
   if (ns > 512) ns = 512;
@@ -690,7 +743,7 @@ extern "C" int ecgmm_conv_wgrad_ring_enable(int on) {
 }
 
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g) {
-  int ns = pick_nsplit(g, dtype == ECGMM_BF16 ? 32 : 16);
+  int ns = pick_nsplit(g, dtype == ECGMM_BF16 ? 32 : 16, 1);   // (upper bound over the kernel variants)
   return (size_t)ns * g.R * g.S * g.Cout * g.Cin * sizeof(float);
 }
 
@@ -702,7 +755,9 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
     ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: channels (%d,%d) must be multiples of %d", g.Cin, g.Cout, vec);
   long M = (long)g.N * g.OH * g.OW;
   if (M <= 0 || M > 0x7fffffffL) ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: pixel count %ld out of range", M);
-  int ns = pick_nsplit(g, kp);
+  const bool ring = wgrad_ring_ok(dtype, g);
+  const int groups = ring ? 1 : wgrad_groups(dtype, g);
+  int ns = pick_nsplit(g, kp, groups);
   size_t need = (size_t)ns * g.R * g.S * g.Cout * g.Cin * sizeof(float);
   if (workspace_bytes < need || !workspace)
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "conv wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -719,7 +774,7 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
                      4.0 * g.R * g.S * g.Cin * g.Cout,
                  stream);
   int rc;
-  if (wgrad_ring_ok(dtype, g)) {
+  if (ring) {
     WgradRingParams q;
     q.x = x; q.dy = dy; q.slab = (float*)workspace;
     q.H = g.H; q.W = g.W; q.Cin = g.Cin; q.Cout = g.Cout; q.pad_h = g.pad_h; q.M = (int)M;
@@ -730,7 +785,7 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
     dim3 grid((g.Cout / 64) * (g.Cin / 64), ns);
     rc = g.R == 3 ? launch_wgrad_ring<9>(q, grid, stream) : launch_wgrad_ring<3>(q, grid, stream);
   } else {
-    rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, stream) : launch_wgrad<float>(g, p, ns, stream);
+    rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, groups, stream) : launch_wgrad<float>(g, p, ns, 1, stream);
   }
   ecg_prof_end(stream);
   ECG_TRY(rc);

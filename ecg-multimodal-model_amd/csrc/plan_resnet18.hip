@@ -18,6 +18,7 @@
 #include "side_stream.h"
 
 namespace {
+long g_fuse_min_m = -1;  // pixel-count threshold of the fused BatchNorm-backward reductions (-1: read ECGMM_BN_FUSE_MIN_M)
 
 struct BlockCfg {
   int cin, cout, stride, hin, win, hout, wout;
@@ -375,8 +376,15 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       bool fused2 = false;
       int fused2_rows = 0;
       // (ECGMM_BN_FUSE=0: always the separate reduction pass -- A/B switch; same results up to fp32 summation order)
+      // Fused only where it pays (serialized trace, profiles/r02_*_v1): on the 56x56 tensors the reduction pass it
+      // replaces costs more HBM time (52 us) than the epilogue adds (20-30 us); from 28x28 down the epilogue's exposed
+      // load latency (one persistent workgroup per CU, 3-4 tiles each) costs MORE than the 10-30 us pass.
+      // ECGMM_BN_FUSE_MIN_M overrides the pixel-count threshold (0 = fuse wherever possible).
       static const bool fuse_on = [] { const char* e = getenv("ECGMM_BN_FUSE"); return !(e && e[0] == '0'); }();
-      if (fuse_on && i + 1 < 8 && !r.blk[i + 1].down) {
+      if (g_fuse_min_m < 0) { const char* e = getenv("ECGMM_BN_FUSE_MIN_M"); g_fuse_min_m = e ? atol(e) : 400000L; }
+      const long fuse_min_m = g_fuse_min_m;
+      const bool fuse_here = fuse_on && M >= fuse_min_m;
+      if (fuse_here && i + 1 < 8 && !r.blk[i + 1].down) {
         const BlockCfg& kn = r.blk[i + 1];
         const ConvGeom gn = make_geom(N, kn.hin, kn.win, kn.cin, kn.cout, 3, 3, 1, 1, 1);
         fused2 = ecg_conv_halo_ok(dt, 1, gn);
@@ -400,7 +408,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       }
       // a1 = relu(bn1(y1)); the mask is recomputed from y1
       ConvEpi ea = {};
-      if (fuse_on) { ea.wg_rows = 1; ea.red_y = b.y1; ea.red_mask = b.y1; ea.red_coef = b.coef1; ea.red_rows = q.red1; }
+      if (fuse_here) { ea.wg_rows = 1; ea.red_y = b.y1; ea.red_mask = b.y1; ea.red_coef = b.coef1; ea.red_rows = q.red1; }
       ECG_TRY(ecg_conv_igemm(dt, 1, g2, dyb, b.w2d, q.da, nullptr, nullptr, nullptr, 0, s, &ea));
       main_wait(s, g_side.done2[1][pp]);
       if (ea.red_done) {
@@ -431,7 +439,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       } else {
         // this conv1 dgrad produces the previous block's output gradient: fuse that block's bn2 reduction (see above)
         ConvEpi eb = {};
-        if (fuse_on && i > 0 && ecg_conv_halo_ok(dt, 1, g1)) {
+        if (fuse_here && i > 0 && ecg_conv_halo_ok(dt, 1, g1)) {
           const FwdWs::B& pb = w.b[i - 1];
           eb.wg_rows = 1; eb.red_y = pb.y2; eb.red_mask = pb.out; eb.red_coef = pb.coef2; eb.red_rows = q.red2;
         }
@@ -462,5 +470,10 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
     (void)hipEventRecord(e, g_side.s);
     (void)hipStreamWaitEvent(s, e, 0);
   }
+  return 0;
+}
+
+extern "C" int ecgmm_bn_fuse_min_pixels(int64_t m) {
+  g_fuse_min_m = m < 0 ? 400000L : (long)m;
   return 0;
 }

@@ -88,6 +88,7 @@ SIGNATURES = {
     "ecgmm_bn_bwd_from_rows": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp]),
     "ecgmm_bnrelu_maxpool": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_maxpool_relu_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ecgmm_bn_fuse_min_pixels": (i32, [i64]),
     "ecgmm_pool_bn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ecgmm_avgpool": (i32, [i32, vp, vp, i32, i32, i32, vp, vp]),
     "ecgmm_bcast_rows": (i32, [i32, vp, vp, i32, i32, i32, f32, vp]),

@@ -216,6 +216,11 @@ int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, con
                            const float* gamma, float* dgamma, float* dbeta, void* dy, const float* rows, int nrows,
                            int64_t M, int C, void* scratch, void* stream);
 
+/* ResNet18 plan: a BatchNorm-backward reduction is fused into the producing dgrad's epilogue only for layers with at
+ * least this many output pixels (default 400000 = the 56x56 stage at batch >= 128; 0 = wherever the halo kernel runs;
+ * negative restores the default).  Start-up value: ECGMM_BN_FUSE_MIN_M.  Results differ by fp32 summation order only. */
+int ecgmm_bn_fuse_min_pixels(int64_t m);
+
 /* relu(bn(y)) -> MaxPool(3,2,1) (resnet18.maxpool; ResNet1D_SE.initial[3], PMB:103) and its backward */
 int ecgmm_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int N, int H, int W,
                          int C, void* stream);

@@ -272,8 +272,19 @@ def _dev_vs_autocast(make_ref, make_net, x, loss_of, keys):
     assert not bad, bad
 
 
+@pytest.fixture(params=["default", "everywhere"])
+def conv_kernel_choice(request):
+    """default: the plans pick kernels/fusions by their size rules (small test shapes -> general kernels, separate passes);
+    everywhere: the halo conv kernel, the ring wgrad kernel and the fused BatchNorm-backward reductions wherever applicable"""
+    from ecgmm.hip import lib as L
+    if request.param == "everywhere":
+        L.lib().ecgmm_conv_halo_enable(2); L.lib().ecgmm_conv_wgrad_ring_enable(2); L.lib().ecgmm_bn_fuse_min_pixels(0)
+    yield request.param
+    L.lib().ecgmm_conv_halo_enable(1); L.lib().ecgmm_conv_wgrad_ring_enable(1); L.lib().ecgmm_bn_fuse_min_pixels(-1)
+
+
 @pytest.mark.parametrize("shape", [(4, 3, 64, 64), (8, 3, 128, 96)])
-def test_resnet18_bf16_no_worse_than_torch_autocast(shape):
+def test_resnet18_bf16_no_worse_than_torch_autocast(shape, conv_kernel_choice):
     sd = fill.hash_fill_module(O.ResNet18(num_classes=256), "r18.").state_dict()
     r = fill.hash_tensor((shape[0], 256), 99)
 

@@ -52,7 +52,9 @@ def halo_everywhere():
     """conv_halo.hip / wgrad_ring_kernel for every shape they can serve (the defaults only pick them where faster)"""
     L.lib().ecgmm_conv_halo_enable(2)
     L.lib().ecgmm_conv_wgrad_ring_enable(2)
+    L.lib().ecgmm_bn_fuse_min_pixels(0)
     yield
+    L.lib().ecgmm_bn_fuse_min_pixels(-1)
     L.lib().ecgmm_conv_halo_enable(1)
     L.lib().ecgmm_conv_wgrad_ring_enable(1)
 

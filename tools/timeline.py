@@ -21,8 +21,8 @@ for q, ks in byq.items():
     gaps = sum(max(0, b["s"] - a["e"]) for a, b in zip(ks, ks[1:]))
     print(f"queue {q}: {len(ks)} launches, busy {busy / 1e3:.1f} us, gaps between its kernels {gaps / 1e3:.1f} us, span {(ks[-1]['e'] - ks[0]['s']) / 1e3:.1f} us")
 def short(n):
-    n = n.split("(")[0]
-    return n.replace("(anonymous namespace)::", "")[:70]
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:70]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in step:
     a = agg[(r["Queue_Id"], short(r["Kernel_Name"]))]
