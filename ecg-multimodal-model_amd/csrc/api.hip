@@ -113,6 +113,23 @@ int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* d
   if (rc == 0 && e.red_done) *nrows = e.red_rows_n;
   return rc;
 }
+int ecgmm_conv_bwd_data_with_downsample(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
+                                        const void* dy_down, const void* w_down_dgrad, void* dx, void* tmp,
+                                        void* stream) {
+  if (!dy_down || !w_down_dgrad) ECG_FAIL(ECGMM_ERR_SHAPE, "conv_bwd_data_with_downsample: null downsample operand");
+  const ConvGeom g = geom_of(c);
+  if (g.stride != 2) ECG_FAIL(ECGMM_ERR_SHAPE, "conv_bwd_data_with_downsample: stride %d (the main convolution must have stride 2)", g.stride);
+  ConvEpi e = {};
+  e.src2 = dy_down; e.wpk2 = w_down_dgrad;
+  ECG_TRY(ecg_conv_igemm(dtype, 1, g, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, S_(stream), &e));
+  if (e.src2_done) return 0;
+  // geometry not served by the folded form: two launches through the caller's temporary (same shape as dx)
+  if (!tmp) ECG_FAIL(ECGMM_ERR_WORKSPACE, "conv_bwd_data_with_downsample: this geometry needs the temporary");
+  ConvGeom gd = g;
+  gd.R = gd.S = 1; gd.pad_h = gd.pad_w = 0;
+  ECG_TRY(ecg_conv_igemm(dtype, 1, gd, dy_down, w_down_dgrad, tmp, nullptr, nullptr, nullptr, 0, S_(stream)));
+  return ecg_conv_igemm(dtype, 1, g, dy, w_dgrad, dx, nullptr, tmp, nullptr, 0, S_(stream));
+}
 int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
                            const float* gamma, float* dgamma, float* dbeta, void* dy, const float* rows, int nrows,
                            int64_t M, int C, void* scratch, void* stream) {

@@ -54,6 +54,11 @@ struct IgemmParams {
   int Nimg, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad_h, pad_w;
   int M;  // destination pixels
   int act;
+  // stride-2 dgrad only (nullable): the gradient of a 1x1 stride-2 pad-0 convolution of the SAME input (a ResNet
+  // downsample branch) -- same [N][Hs][Ws][Cs] shape as src -- and its dgrad-packed weights [Cd][1][Cs]; it is one more
+  // "tap" of parity class (0,0) (a 3x3 pad-1 class (0,0) holds the centre tap only: both read source pixel (h/2, w/2))
+  const void* src2;
+  const void* wpk2;
 };
 
 #ifdef ECG_STAMP
@@ -166,18 +171,41 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   }
   const int RS = p.R * p.S;
   const int cpt = (p.Cs + KBE - 1) / KBE;  // stages per tap
-  const int nk = Rc * Sc * cpt;
+  const int nk_main = Rc * Sc * cpt;
+  const bool has2 = PAR && p.src2 != nullptr && blockIdx.z == 0;   // block-uniform
+  const int nk = nk_main + (has2 ? cpt : 0);
   unsigned wrow[NWV];
 #pragma unroll
   for (int i = 0; i < NWV; ++i) {
     int j = n0 + wave * (BN / 4) + i * 8 + lrow8;
     wrow[i] = j < p.Cd ? (unsigned)j * (unsigned)RS * pix_bytes : OOB;
   }
+  const __amdgpu_buffer_rsrc_t rs_src2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const T*)(has2 ? p.src2 : p.src) + (size_t)n_first * img_elems), 0,
+      left > 0xFFFFFFF0ull ? (int)0xFFFFFFF0u : (int)left, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(has2 ? p.wpk2 : p.wpk), 0, (int)((size_t)p.Cd * p.Cs * sizeof(T)), 0x00020000);
+  int g_n = 0;  // stages issued so far (wave-uniform)
 
   int g_r = 0, g_s = 0, g_cc = 0;  // wave-uniform tap / channel-stage counters (stages are issued in order)
   auto dma = [&](int stage) {
     unsigned char* sW = smem + stage * STAGE_BYTES;
     unsigned char* sX = sW + BN * ROWB;
+    if (PAR && g_n >= nk_main) {   // the folded 1x1 branch: source pixel (hq, wq) itself, its own weights [Cd][Cs]
+      const int ch = (g_n - nk_main) * KBE + lchunk * VEC;
+      const unsigned chb = ch < p.Cs ? (unsigned)ch * (unsigned)sizeof(T) : OOB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = (unsigned)hq[i] < (unsigned)p.Hs && (unsigned)wq[i] < (unsigned)p.Ws;
+        dma16(rs_src2, sX + (wv * 4 + i) * 1024, (ok && chb != OOB) ? offb[i] + chb : OOB);
+      }
+#pragma unroll
+      for (int i = 0; i < NWV; ++i)
+        dma16(rs_w2, sW + (wv * NWV + i) * 1024, (wrow[i] != OOB && chb != OOB) ? wrow[i] / (unsigned)RS + chb : OOB);
+      ++g_n;
+      return;
+    }
+    ++g_n;
     const int r = r0 + g_r * TSTEP, s = s0 + g_s * TSTEP;
     const int ch = g_cc * KBE + lchunk * VEC;
     const unsigned chb = ch < p.Cs ? (unsigned)ch * (unsigned)sizeof(T) : OOB;
@@ -582,9 +610,15 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
     double bytes = esz * ((double)g.N * p.Hs * p.Ws * p.Cs + (double)M * p.Cd * (addend ? 2.0 : 1.0) +
                           (double)g.R * g.S * g.Cin * g.Cout);
     if (epi && epi->red_y) bytes += esz * (double)M * p.Cd * (epi->red_mask ? 2.0 : 1.0);  // fused BN-backward reduction operands
+    if (epi && epi->src2 && mode == 1 && g.stride == 2) bytes += esz * ((double)g.N * p.Hs * p.Ws * p.Cs + (double)g.Cin * g.Cout);
     ecg_prof_begin(dtype == ECGMM_F32 ? (mode == 0 ? ECG_PROF_IGEMM_F32_FWD : ECG_PROF_IGEMM_F32_DGRAD)
                                       : (mode == 0 ? ECG_PROF_IGEMM_FWD : ECG_PROF_IGEMM_DGRAD),
                    conv_flops(g), bytes, stream);
+  }
+  if (epi) epi->src2_done = 0;
+  if (epi && epi->src2 && mode == 1 && g.stride == 2 && g.pad_h <= 1 && g.pad_w <= 1 && !addend) {
+    p.src2 = epi->src2; p.wpk2 = epi->wpk2;
+    epi->src2_done = 1;
   }
   int rc;
   if (ecg_conv_halo_ok(dtype, mode, g)) {  // stride-1 3x3 / 1x3 on whole 256-pixel tiles: halo-resident kernel (conv_halo.hip)

@@ -13,7 +13,13 @@ struct ConvEpi {
   const float* red_coef;  // that BatchNorm's forward coefficients [4][C]
   float* red_rows;        // [>= 256 rows][2][C]
   int wg_rows;            // in: 1 = the launch may write ONE partial row per workgroup instead of one per 64 pixels
+  // in -- stride-2 dgrad only: fold the input gradient of a 1x1 stride-2 pad-0 convolution of the same input (ResNet
+  // downsample branch) into this launch: src2 = that branch's output gradient (same shape as src), wpk2 = its dgrad pack.
+  // Done by the parity-class kernel only: check src2_done (0 = run it as its own launch and pass the result as addend).
+  const void* src2;
+  const void* wpk2;
   // out
+  int src2_done;
   int stats_rows;         // rows of `stats` the forward launch wrote
   int red_done;           // 1 = red_rows holds red_rows_n rows; 0 = the caller runs the separate reduction pass
   int red_rows_n;

@@ -381,6 +381,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       // load latency (one persistent workgroup per CU, 3-4 tiles each) costs MORE than the 10-30 us pass.
       // ECGMM_BN_FUSE_MIN_M overrides the pixel-count threshold (0 = fuse wherever possible).
       static const bool fuse_on = [] { const char* e = getenv("ECGMM_BN_FUSE"); return !(e && e[0] == '0'); }();
+      static const bool fold_on = [] { const char* e = getenv("ECGMM_DOWN_FOLD"); return !(e && e[0] == '0'); }();
       if (g_fuse_min_m < 0) { const char* e = getenv("ECGMM_BN_FUSE_MIN_M"); g_fuse_min_m = e ? atol(e) : 400000L; }
       const long fuse_min_m = g_fuse_min_m;
       const bool fuse_here = fuse_on && M >= fuse_min_m;
@@ -434,8 +435,18 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
           ECG_TRY(ecg_conv_wgrad(dt, gd, in, dydb, G(grads, k.p_dconv), 0, q.wg_ws, q.wg_bytes, ws));
           if (side) g_side.done2[2][pp] = side_mark();
         }
-        ECG_TRY(ecg_conv_igemm(dt, 1, gd, dydb, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+        // the downsample branch's input gradient is one more tap of the stride-2 dgrad's parity class (0,0): one launch,
+        // no [N][H][W][Cin] temporary written and re-read as addend
+        ConvEpi ed = {};
+        ed.src2 = dydb; ed.wpk2 = b.wdd;
+        if (!fold_on) ed.src2 = nullptr;
+        if (ed.src2) {
+          ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, nullptr, nullptr, 0, s, &ed));
+        }
+        if (!ed.src2_done) {
+          ECG_TRY(ecg_conv_igemm(dt, 1, gd, dydb, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
+          ECG_TRY(ecg_conv_igemm(dt, 1, g1, dy1b, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+        }
       } else {
         // this conv1 dgrad produces the previous block's output gradient: fuse that block's bn2 reduction (see above)
         ConvEpi eb = {};

@@ -370,8 +370,14 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
           ECG_TRY(ecg_conv_wgrad(dt, gd, in, q.dyd, G(grads, p + 12), 0, q.wg_ws, q.wg_bytes, wst));
           if (side) g_side1.doneC = g_side1.mark();
         }
-        ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.dyd, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
-        ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+        static const bool fold_on = [] { const char* e = getenv("ECGMM_DOWN_FOLD"); return !(e && e[0] == '0'); }();
+        ConvEpi ed = {};   // downsample branch folded into the stride-2 dgrad (see plan_resnet18.hip)
+        if (fold_on) { ed.src2 = q.dyd; ed.wpk2 = b.wdd; }
+        if (ed.src2) ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, nullptr, nullptr, 0, s, &ed));
+        if (!ed.src2_done) {
+          ECG_TRY(ecg_conv_igemm(dt, 1, gd, q.dyd, b.wdd, q.dtmp, nullptr, nullptr, nullptr, 0, s));
+          ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dtmp, nullptr, 0, s));
+        }
       } else {
         ECG_TRY(ecg_conv_igemm(dt, 1, g1, q.dy1, b.w1d, din, nullptr, q.dz, nullptr, 0, s));
       }

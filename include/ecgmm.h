@@ -212,6 +212,15 @@ int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* 
 int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
                               const void* addend, void* dx, const void* bn_y, const void* bn_mask, const float* bn_coef,
                               float* rows, int* nrows, void* stream);
+/* Input gradient of a ResNet stage-entry block's two stride-2 branches in one launch (torchvision BasicBlock with
+ * downsample; BasicBlock1D, multimodal_paper_modal_balance.py:71-93):  dx = dgrad(conv c, dy) + dgrad(1x1 stride-2 pad-0
+ * conv of the same input, dy_down).  The 1x1 branch is one more tap of the stride-2 kernel's parity class (0,0); no
+ * temporary is written.  c describes the main convolution (3x3 or 1x3, stride 2, pad <= 1); both gradients are
+ * [N][OH][OW][Cout], w_down_dgrad is the 1x1 weight packed for dgrad.  tmp (same size as dx) is only used for geometries
+ * the folded form does not serve; NULL is accepted when c has stride 2 and pad <= 1. */
+int ecgmm_conv_bwd_data_with_downsample(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
+                                        const void* dy_down, const void* w_down_dgrad, void* dx, void* tmp,
+                                        void* stream);
 int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
                            const float* gamma, float* dgamma, float* dbeta, void* dy, const float* rows, int nrows,
                            int64_t M, int C, void* scratch, void* stream);

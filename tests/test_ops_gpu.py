@@ -119,6 +119,39 @@ def test_conv_fwd_dgrad_wgrad(case, dt, halo_everywhere):
     assert rel_err(dw.cpu(), 2 * w.grad) < 3e-5
 
 
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("case", [(4, 16, 16, 64, 128, 3), (3, 14, 10, 128, 256, 3), (2, 9, 7, 64, 64, 3),
+                                  (5, 1, 62, 64, 128, 1), (3, 1, 45, 128, 256, 1)])
+def test_stride2_dgrad_with_folded_downsample_branch(case, dt):
+    """dx of a stage-entry block's two stride-2 branches in one launch == torch autograd of conv3x3/s2(x) and conv1x1/s2(x)
+    (torchvision BasicBlock.downsample; BasicBlock1D, multimodal_paper_modal_balance.py:71-93)"""
+    N, H, W, Cin, Cout, R = case
+    lib = L.lib()
+    ph = 1 if R == 3 else 0
+    x = fill.hash_tensor((N, Cin, H, W), 61)
+    w = fill.hash_tensor((Cout, Cin, R, 3), 62, (2.0 / (Cin * R * 3)) ** 0.5)
+    wd_ = fill.hash_tensor((Cout, Cin, 1, 1), 63, (2.0 / Cin) ** 0.5)
+    if dt == L.BF16:
+        x, w, wd_ = bf16_round(x), bf16_round(w), bf16_round(wd_)
+    x.requires_grad_(True)
+    y1 = F.conv2d(x, w, None, 2, (ph, 1))
+    y2 = F.conv2d(x, wd_, None, 2, 0)
+    assert y1.shape == y2.shape
+    dy1, dy2 = fill.hash_tensor(tuple(y1.shape), 64), fill.hash_tensor(tuple(y1.shape), 65)
+    if dt == L.BF16:
+        dy1, dy2 = bf16_round(dy1), bf16_round(dy2)
+    ((y1 * dy1).sum() + (y2 * dy2).sum()).backward()
+    d = conv_desc(N, H, W, Cin, Cout, R, 3, 2, ph, 1)
+    _, wpk = pack_weight(w.detach(), dt)
+    _, wpk2 = pack_weight(wd_.detach(), dt)
+    dxg = torch.empty(N * H * W * Cin, device=DEV, dtype=TDT[dt])
+    g1, g2 = to_nhwc(dy1, dt), to_nhwc(dy2, dt)
+    L.check(lib.ecgmm_conv_bwd_data_with_downsample(dt, C.byref(d), ptr(g1), ptr(wpk), ptr(g2), ptr(wpk2), ptr(dxg), None,
+                                                     stream()))
+    dx = from_nhwc(dxg, dt, x.shape)
+    assert rel_err(dx, x.grad) < (2e-5 if dt == L.F32 else 6e-3)
+
+
 def test_conv_halo_kernel_agrees_with_the_general_kernel():
     """same launch through both bf16 kernels (ecgmm_conv_halo_enable): identical products, other fp32 summation order"""
     lib = L.lib()
