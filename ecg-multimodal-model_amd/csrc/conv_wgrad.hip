@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
   unsigned char* const smem_g = smem + grp * 2 * STAGE_BYTES;
-  const int wco = wave & 1, wci = wave >> 1;
+  // Wave layout: every wave owns ALL 64 output channels (4 dy fragments, loaded once per K step and reused by every
+  // tap) x its own 16 input channels (one x fragment per tap): 4 + NT fragment reads per 4 NT MFMAs.  The 2 x 2 layout
+  // (32 x 32 per wave) read 2 + 2 NT fragments for the same MFMAs -- 0.56 vs 0.36 KB of LDS per MFMA at 9 taps, and the
+  // LDS read bytes of two resident workgroups were 110 % of their MFMA time.
+  constexpr int TA = 4, TB = 1;
   const int ci_tiles = (p.Cin + 63) / 64;
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest).  All (co, ci)
   // tiles of one split read the same pixels of x and dy, so a split's tiles are steered onto ONE XCD (its operand
@@ -112,13 +116,13 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
   const int s_end = GROUPS == 1 ? wg_end : min(wg_end, s_begin + iters);
   const int my_len = max(s_end - s_begin, 0);
 
-  f32x4 acc[NT][2][2];
+  f32x4 acc[NT][TA][TB];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < TB; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- DMA bookkeeping: this lane fills (row = wave*RPP + lane/CPR, physical chunk lane%CPR) of every tile
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -212,18 +216,18 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
         uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         return (u32x4){l2.x, l2.y, h2.x, h2.y};
       };
-      u32x4 fa[2];
+      u32x4 fa[TA];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = frag(st, wco * 32 + a * 16);
+      for (int a = 0; a < TA; ++a) fa[a] = frag(st, a * 16);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        u32x4 fb[2];
+        u32x4 fb[TB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) fb[b] = frag(st + (1 + t) * TILE_BYTES, wci * 32 + b * 16);
+        for (int b = 0; b < TB; ++b) fb[b] = frag(st + (1 + t) * TILE_BYTES, wave * 16 + b * 16);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < TB; ++b)
             acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
                                                                    __builtin_bit_cast(bf16x8_t, fb[b]),
                                                                    acc[t][a][b], 0, 0, 0);
@@ -236,18 +240,18 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
         auto rd = [&](const unsigned char* tile, int col) -> float {
           return *reinterpret_cast<const float*>(tile + krow * C::RB + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
         };
-        float fa[2];
+        float fa[TA];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) fa[a] = rd(st, wco * 32 + a * 16 + fr);
+        for (int a = 0; a < TA; ++a) fa[a] = rd(st, a * 16 + fr);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          float fb[2];
+          float fb[TB];
 #pragma unroll
-          for (int b = 0; b < 2; ++b) fb[b] = rd(st + (1 + t) * TILE_BYTES, wci * 32 + b * 16 + fr);
+          for (int b = 0; b < TB; ++b) fb[b] = rd(st + (1 + t) * TILE_BYTES, wave * 16 + b * 16 + fr);
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
+          for (int a = 0; a < TA; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < TB; ++b)
               acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[t][a][b], 0, 0, 0);
         }
       }
@@ -300,34 +304,34 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < TB; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) red[(((t * 2 + a) * 2 + b) * 4 + j) * 256] = acc[t][a][b][j];
+            for (int j = 0; j < 4; ++j) red[(((t * TA + a) * TB + b) * 4 + j) * 256] = acc[t][a][b][j];
     }
     __syncthreads();
     if (grp == 1) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TB; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][a][b][j] += red[(((t * 2 + a) * 2 + b) * 4 + j) * 256];
+          for (int j = 0; j < 4; ++j) acc[t][a][b][j] += red[(((t * TA + a) * TB + b) * 4 + j) * 256];
   }
 
   // ---- slab store: D[row = co][col = ci]; lane: ci = fr, co = fq*4 + j
   const int RS = NT;
   if (co0 + 64 <= p.Cout && ci0 + 64 <= p.Cin) {  // whole tile in range: no per-element branches
-    float* base = p.slab + (((size_t)split * RS) * p.Cout + co0 + wco * 32 + fq * 4) * p.Cin + ci0 + wci * 32 + fr;
+    float* base = p.slab + (((size_t)split * RS) * p.Cout + co0 + fq * 4) * p.Cin + ci0 + wave * 16 + fr;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TB; ++b)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             base[((size_t)t * p.Cout + a * 16 + j) * p.Cin + b * 16] = acc[t][a][b][j];
@@ -336,13 +340,13 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_kernel(WgradParams p) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        int ci = ci0 + wci * 32 + b * 16 + fr;
+      for (int b = 0; b < TB; ++b) {
+        int ci = ci0 + wave * 16 + b * 16 + fr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          int co = co0 + wco * 32 + a * 16 + fq * 4 + j;
+          int co = co0 + a * 16 + fq * 4 + j;
           if (co < p.Cout && ci < p.Cin)
             p.slab[(((size_t)split * RS + t) * p.Cout + co) * p.Cin + ci] = acc[t][a][b][j];
         }
@@ -412,15 +416,19 @@ __device__ __forceinline__ u32x4 ring_rsrc(const void* ptr, size_t bytes) {
                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bytes), 0x00020000u};
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
+// GROUPS = 2: two 4-wave groups per 512-thread workgroup, each with its own ring / dy stages over its half of the
+// workgroup's steps, one slab tile per workgroup (LDS hand-over at the end) -- as wgrad_kernel<T, NT, 2>.
+template <int NT, int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParams p) {
   using C = WgCfg<bf16_t>;
   constexpr int R = NT / 3;  // filter rows (S == 3)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int wco = wave & 1, wci = wave >> 1;
+  const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
+  unsigned char* const smem = smem_wg + grp * RING_LDS;
+  constexpr int TA = 4;   // wave layout as in wgrad_kernel: all 64 output channels x the wave's own 16 input channels
   const int ci_tiles = p.Cin / 64;
   int tile_id = blockIdx.x, split = blockIdx.y;
   if ((gridDim.y & 7) == 0 && gridDim.x > 1) {   // a split's tiles on one XCD (see wgrad_kernel)
@@ -433,17 +441,18 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
   const bf16_t* __restrict__ x = (const bf16_t*)p.x;
   const bf16_t* __restrict__ dy = (const bf16_t*)p.dy;
   const int total_steps = (p.M + 31) / 32;
-  const int s_begin = split * p.steps_per_split;
-  const int s_end = min(total_steps, s_begin + p.steps_per_split);
+  const int wg_begin = split * p.steps_per_split;
+  const int wg_len = max(min(total_steps, wg_begin + p.steps_per_split) - wg_begin, 0);
+  const int iters = GROUPS == 1 ? wg_len : (wg_len + 1) / 2;   // group 0's step count (>= group 1's)
+  const int s_begin = wg_begin + grp * iters;
+  const int s_end = min(wg_begin + wg_len, s_begin + iters);
 
-  f32x4 acc[NT][2][2];
+  f32x4 acc[NT][TA];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (tid < 8) *reinterpret_cast<u32x4*>(smem + RING_ZERO + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+    for (int a = 0; a < TA; ++a) acc[t][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if ((tid & 255) < 8) *reinterpret_cast<u32x4*>(smem + RING_ZERO + (tid & 255) * 16) = (u32x4){0u, 0u, 0u, 0u};
 
   // ---- DMA bookkeeping (whole tensors are addressed from their start: the host keeps them under 2 GiB)
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
   for (int t = 0; t < NT; ++t) {
     const int r = t / 3, sx = t - r * 3;
     const int d = (r - p.pad_h) * p.W + (sx - 1);
-    const int byte0 = wci * 64 + 8 * pq;
+    const int byte0 = wave * 32 + 8 * pq;
     const int rl = (P0 + kl + d) & (RING_ROWS - 1), rh = (P0 + kl + 4 + d) & (RING_ROWS - 1);
     A_lo[t] = (unsigned)(rl * 128 + ((((byte0 >> 4) ^ C::swz(rl))) << 4) + (byte0 & 15));
     A_hi[t] = (unsigned)(rh * 128 + ((((byte0 >> 4) ^ C::swz(rh))) << 4) + (byte0 & 15));
@@ -504,10 +513,10 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
     // dy fragments (A operand): the step's own tile, rows 8 fq + q (+ 4), as in wgrad_kernel
     const int row = 8 * fq + q4;
     const int sw = C::swz(row);
-    u32x4 fa[2];
+    u32x4 fa[TA];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int byte = (wco * 32 + a * 16 + 4 * pq) * 2;
+    for (int a = 0; a < TA; ++a) {
+      const int byte = (a * 16 + 4 * pq) * 2;
       const unsigned char* a0 = dyt + row * 128 + ((((byte >> 4) ^ sw)) << 4) + (byte & 15);
       s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0)));
       s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0 + 512)));
@@ -540,29 +549,23 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
       al[t] = (hl_[r] && wl_[sx]) ? ((A_lo[t] + rot) & (RING_BYTES - 1)) : zrow;
       ah[t] = (hh_[r] && wh_[sx]) ? ((A_hi[t] + rot) & (RING_BYTES - 1)) : zrow;
     }
-    auto rd_tap = [&](int t, u32x4 (&fb)[2]) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        // column block b: +16 channels = +2 chunks = bit 1 of the chunk index, untouched by the swizzle's XOR pattern
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + (al[t] ^ (b * 32))));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + (ah[t] ^ (b * 32))));
-        uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        fb[b] = (u32x4){l2.x, l2.y, h2.x, h2.y};
-      }
+    auto rd_tap = [&](int t, u32x4& fb) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + al[t]));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + ah[t]));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      fb = (u32x4){l2.x, l2.y, h2.x, h2.y};
     };
-    u32x4 fbA[2], fbB[2];
+    u32x4 fbA, fbB;
     rd_tap(0, fbA);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      u32x4 (&cur)[2] = (t & 1) ? fbB : fbA;
-      u32x4 (&nxt)[2] = (t & 1) ? fbA : fbB;
+      u32x4& cur = (t & 1) ? fbB : fbA;
+      u32x4& nxt = (t & 1) ? fbA : fbB;
       if (t + 1 < NT) rd_tap(t + 1, nxt);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
-                                                                 __builtin_bit_cast(bf16x8_t, cur[b]), acc[t][a][b], 0, 0, 0);
+      for (int a = 0; a < TA; ++a)
+        acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                            __builtin_bit_cast(bf16x8_t, cur), acc[t][a], 0, 0, 0);
     }
     // next step: 32 pixels on
     st_ow += d_ow;
@@ -572,43 +575,66 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradRingParams p) {
     if (st_oh >= p.H) st_oh -= p.H;
   };
 
-  const int nsteps = s_end - s_begin;
-  if (nsteps > 0) {
+  const int nsteps = max(s_end - s_begin, 0);
+  if (iters > 0) {   // (every wave of the workgroup takes the same `iters` trips: the barriers are workgroup-wide)
     // prologue: the window of the first step, [P0 - HLa, P0 + 32 + HLa), its dy tile, and the fill groups of the next
     // RING_D - 1 steps; everything waited for once
-    for (int pc = wv; pc * 8 < 32 + 2 * p.HLa; pc += 4) x_piece(P0 - p.HLa + pc * 8);
-    dy_piece(0, s_begin);
-    for (int j = 1; j < RING_D && j < nsteps; ++j) dma_step(j, s_begin + j);
+    if (nsteps > 0) {
+      for (int pc = wv; pc * 8 < 32 + 2 * p.HLa; pc += 4) x_piece(P0 - p.HLa + pc * 8);
+      dy_piece(0, s_begin);
+      for (int j = 1; j < RING_D && j < nsteps; ++j) dma_step(j, s_begin + j);
+    }
     ring_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // (the zero row's ds_write is covered by the lgkmcnt wait hipcc puts before it)
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the zero row's ds_write
+    __builtin_amdgcn_s_barrier();
     unsigned rot = 0u;
-    for (int k = 0; k < nsteps; ++k) {
-      // fills RING_D steps ahead: dy stage (k + RING_D) & 3 was read in step k - 1 (every wave is past its barrier); the
-      // ring slots they overwrite hold pixels 256 rows back, behind this step's window (host: HL + HLa + 32 RING_D + 32 <= 256)
-      if (k + RING_D < nsteps) dma_step((k + RING_D) % RING_NDY, s_begin + k + RING_D);
-      compute(k % RING_NDY, rot);
-      rot = (rot + 4096u) & (RING_BYTES - 1);
-      // step k + 1's fills have landed: all but the groups of the steps after it (2 DMAs each) -- this wave's, then
-      // (barrier) everybody's; the LDS reads of this step are back, so its dy stage and ring rows may be overwritten
-      const int younger = (k + RING_D < nsteps ? k + RING_D : nsteps - 1) - (k + 1);
-      if (younger >= 2) ring_wait_vmcnt<4>();
-      else if (younger == 1) ring_wait_vmcnt<2>();
-      else ring_wait_vmcnt<0>();
+    for (int k = 0; k < iters; ++k) {
+      if (GROUPS == 1 || k < nsteps) {
+        // fills RING_D steps ahead: dy stage (k + RING_D) & 3 was read in step k - 1 (every wave is past its barrier); the
+        // ring slots they overwrite hold pixels 256 rows back, behind this step's window (host: HL + HLa + 32 RING_D + 32 <= 256)
+        if (k + RING_D < nsteps) dma_step((k + RING_D) % RING_NDY, s_begin + k + RING_D);
+        compute(k % RING_NDY, rot);
+        rot = (rot + 4096u) & (RING_BYTES - 1);
+        // step k + 1's fills have landed: all but the groups of the steps after it (2 DMAs each) -- this wave's, then
+        // (barrier) everybody's; the LDS reads of this step are back, so its dy stage and ring rows may be overwritten
+        const int younger = (k + RING_D < nsteps ? k + RING_D : nsteps - 1) - (k + 1);
+        if (younger >= 2) ring_wait_vmcnt<4>();
+        else if (younger == 1) ring_wait_vmcnt<2>();
+        else ring_wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
     }
   }
 
+  if constexpr (GROUPS == 2) {   // group 1 -> LDS -> group 0 (see wgrad_kernel)
+    float* red = reinterpret_cast<float*>(smem_wg) + (tid & 255);
+    if (grp == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) red[((t * TA + a) * 4 + j) * 256] = acc[t][a][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][a][j] += red[((t * TA + a) * 4 + j) * 256];
+  }
+
   // ---- slab store (identical layout to wgrad_kernel: [split][tap][co][ci])
-  float* base = p.slab + (((size_t)split * NT) * p.Cout + co0 + wco * 32 + fq * 4) * p.Cin + ci0 + wci * 32 + fr;
+  float* base = p.slab + (((size_t)split * NT) * p.Cout + co0 + fq * 4) * p.Cin + ci0 + wave * 16 + fr;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) base[((size_t)t * p.Cout + a * 16 + j) * p.Cin + b * 16] = acc[t][a][b][j];
+      for (int j = 0; j < 4; ++j) base[((size_t)t * p.Cout + a * 16 + j) * p.Cin] = acc[t][a][j];
 }
 
 // exact unsigned division by d for dividends < 2^31: q = (x * m) >> sh
@@ -704,21 +730,22 @@ bool wgrad_ring_ok(int dtype, const ConvGeom& g) {
   const double M = (double)g.N * g.H * g.W;
   if (!(M * g.Cin * 2.0 < 2.0e9 && M * g.Cout * 2.0 < 2.0e9)) return false;
   if (g_wgrad_ring == 2) return true;
-  // Same-call A/B at B = 256 (profiles/r02_wgrad_ring_ab.txt): +10 % on the 64-channel 3x3 layers and +3...6 % on the
-  // 1-D k = 3 layers; 5-8 % SLOWER on the 128-512-channel 3x3 layers, although it moves a fifth of the operand bytes,
-  // keeps fills three steps ahead and reads fragments a tap ahead -- those launches are bound by their 75 MB of fp32
-  // split-K slabs (write + re-read by the reduce kernel), not by the K loop.
-  return g.R == 1 || g.Cin == 64;
+  // Same-call A/B at B = 256 with the 4 x 1 wave layout (profiles/r02_wgrad_ring_ab.txt, second table): the ring form is
+  // 5-8 % faster on every 3x3 layer and on the 128/256-channel 1-D k = 3 layers, 12 % slower on the 64-channel 1-D layer
+  // (its halo is a small share of a 1250-pixel row; wgrad_kernel's two-group form wins there).
+  return g.R == 3 || g.Cin >= 128;
 }
 
-template <int NT>
+template <int NT, int GROUPS>
 int launch_wgrad_ring(const WgradRingParams& p, dim3 grid, hipStream_t stream) {
+  int lds = GROUPS * RING_LDS;
+  if (GROUPS == 2 && lds < NT * 16 * 1024) lds = NT * 16 * 1024;   // the hand-over buffer
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_ring_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
+    (void)hipFuncSetAttribute((const void*)wgrad_ring_kernel<NT, GROUPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_ring_kernel<NT>), grid, dim3(256), RING_LDS, stream, p);
+  hipLaunchKernelGGL((wgrad_ring_kernel<NT, GROUPS>), grid, dim3(256 * GROUPS), lds, stream, p);
   ECG_CHECK_LAUNCH("wgrad_ring_kernel");
   return 0;
 }
@@ -756,7 +783,7 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
   long M = (long)g.N * g.OH * g.OW;
   if (M <= 0 || M > 0x7fffffffL) ECG_FAIL(ECGMM_ERR_SHAPE, "conv wgrad: pixel count %ld out of range", M);
   const bool ring = wgrad_ring_ok(dtype, g);
-  const int groups = ring ? 1 : wgrad_groups(dtype, g);
+  const int groups = wgrad_groups(dtype, g);
   int ns = pick_nsplit(g, kp, groups);
   size_t need = (size_t)ns * g.R * g.S * g.Cout * g.Cin * sizeof(float);
   if (workspace_bytes < need || !workspace)
@@ -783,7 +810,8 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
     q.HLa = (q.HL + 7) / 8 * 8;
     q.mul_hw = p.mul_hw; q.sh_hw = p.sh_hw; q.mul_w = p.mul_w; q.sh_w = p.sh_w;
     dim3 grid((g.Cout / 64) * (g.Cin / 64), ns);
-    rc = g.R == 3 ? launch_wgrad_ring<9>(q, grid, stream) : launch_wgrad_ring<3>(q, grid, stream);
+    if (groups == 2) rc = g.R == 3 ? launch_wgrad_ring<9, 2>(q, grid, stream) : launch_wgrad_ring<3, 2>(q, grid, stream);
+    else rc = g.R == 3 ? launch_wgrad_ring<9, 1>(q, grid, stream) : launch_wgrad_ring<3, 1>(q, grid, stream);
   } else {
     rc = dtype == ECGMM_BF16 ? launch_wgrad<bf16_t>(g, p, ns, groups, stream) : launch_wgrad<float>(g, p, ns, 1, stream);
   }
