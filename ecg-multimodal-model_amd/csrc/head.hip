@@ -561,6 +561,12 @@ int ecg_varloss_fwd(const float* f0, const float* f1, const float* f2, int B, in
   ECG_CHECK_LAUNCH("varloss_fwd");
   return 0;
 }
+// scratch already holds the three row-variance vectors [3][B] (head_rows_fwd_kernel): loss + sign coefficients only
+int ecg_varloss_finish(float* scratch, int B, float* loss, hipStream_t s) {
+  hipLaunchKernelGGL(varloss_finish_kernel, dim3(1), dim3(256), 0, s, scratch, B, loss, scratch + 3 * (size_t)B);
+  ECG_CHECK_LAUNCH("varloss_finish");
+  return 0;
+}
 int ecg_varloss_bwd(const float* f, int B, int D, const float* gout, const float* scratch, int m, float* df,
                     int accumulate, hipStream_t s) {
   hipLaunchKernelGGL(varloss_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, s, f, B, D, gout,

@@ -105,6 +105,29 @@ size_t ecg_layernorm_bwd_scratch(int B, int D);
 int ecg_layernorm_bwd(const float* const* seg, const int* dims, int nseg, const float* fusion_w, const float* gamma,
                       const float* stat, const float* dout, float* const* dseg, int dseg_accumulate, float* dgamma,
                       float* dbeta, float* dfusion_w, int B, float* scratch, hipStream_t s);
+// head_fused.hip: the head's row-local work as one kernel per direction + one-wave-per-tile dense kernels
+bool ecg_head_fused_ok(const int* dim, int B, int hidden, int num_classes);
+int ecg_head_partial_floats(const int* dim, int num_classes);
+int ecg_head_bwd_blocks(int B);
+int ecg_head_rows_fwd(const float* const* raw, const float* const* ln_g, const float* const* ln_b,
+                      const float* const* cls_w, const float* const* cls_b, const float* aw, const float* fg,
+                      const float* fb, float* const* feat, float* const* stat, float* const* logits, float* rowvar,
+                      float* fused, float* statf, float* soft_w, const int* dim, int B, int NC, float eps,
+                      hipStream_t s);
+int ecg_head_rows_bwd(const float* const* raw, const float* const* ln_g, const float* const* cls_w, const float* aw,
+                      const float* fg, const float* const* feat, const float* const* stat, const float* statf,
+                      const float* dfused, const float* const* dlog, const float* dvar, const float* gs,
+                      float* const* draw, const int* have, float* partial, const int* dim, int B, int NC,
+                      hipStream_t s);
+int ecg_head_finalize(const float* partial, int rows, const int* dim, int NC, float* const* g_ln, float* const* g_cls,
+                      float* g_aw, float* g_fg, float* g_fb, const float* aw, const int* have, const int* have_cls,
+                      int have_fusion, const float* dz, int B, int H, float* fc0_db, hipStream_t s);
+bool ecg_dense16_ok(const void* a, const void* b, const void* c, int B, int In, int Out);
+int ecg_dense16_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, int act,
+                    hipStream_t s);
+int ecg_dense16_dgrad(const float* dy, const float* w, float* dx, int B, int In, int Out, hipStream_t s);
+int ecg_dense16_wgrad(const float* dy, const float* x, float* dw, int B, int In, int Out, hipStream_t s);
+int ecg_varloss_finish(float* scratch, int B, float* loss, hipStream_t s);
 int ecg_varloss_fwd(const float* f0, const float* f1, const float* f2, int B, int D0, int D1, int D2, float* loss,
                     float* scratch, hipStream_t s);
 int ecg_varloss_bwd(const float* f, int B, int D, const float* gout, const float* scratch, int m, float* df,

@@ -66,6 +66,7 @@ struct HeadBwdWs {
   float* ln_scr;
   void* lin_scr;
   size_t lin_bytes;
+  float* partial;   // head_rows_bwd_kernel's per-block partial rows (fused path)
   size_t bytes;
 };
 
@@ -92,6 +93,7 @@ void layout_bwd(const ecgmm_head_desc& d, void* base, HeadBwdWs& w) {
   }
   w.lin_scr = a.take_bytes(lin);
   w.lin_bytes = lin;
+  w.partial = a.take<float>((size_t)ecg_head_bwd_blocks(d.B) * ecg_head_partial_floats(d.dim, d.num_classes > 4 ? 4 : d.num_classes));
   w.bytes = align_up(a.off, 256);
 }
 
@@ -123,6 +125,26 @@ extern "C" int ecgmm_head_forward(const ecgmm_head_desc* d, const float* const* 
   layout(*d, ws, w);
   if (!ws || ws_bytes < w.bytes) ECG_FAIL(ECGMM_ERR_WORKSPACE, "head fwd: workspace %zu < %zu", ws_bytes, w.bytes);
   const int B = d->B, D = d->dim[0] + d->dim[1] + d->dim[2], H = d->hidden, NC = d->num_classes;
+  if (ecg_head_fused_ok(d->dim, B, H, NC)) {
+    // row-local part in one launch (head_fused.hip), Linear(D -> H) one wave per 16x16 tile
+    const float *ln_g[3], *ln_b[3], *cls_w[3], *cls_b[3];
+    float* lg[3] = {logits[0], logits[1], logits[2]};
+    for (int m = 0; m < 3; ++m) {
+      ln_g[m] = P(params, P_LN + 2 * m); ln_b[m] = P(params, P_LN + 2 * m + 1);
+      cls_w[m] = P(params, P_CLS + 2 * m); cls_b[m] = P(params, P_CLS + 2 * m + 1);
+    }
+    ECG_TRY(ecg_head_rows_fwd(raw, ln_g, ln_b, cls_w, cls_b, P(params, P_AW), P(params, P_ALN), P(params, P_ALN + 1),
+                              w.feat, w.stat, lg, w.vscr, w.fused, w.statf, soft_w, d->dim, B, NC, d->ln_eps, s));
+    if (ecg_dense16_ok(w.fused, P(params, P_FC0), w.h, B, D, H))
+      ECG_TRY(ecg_dense16_fwd(w.fused, P(params, P_FC0), P(params, P_FC0 + 1), w.h, B, D, H, ECGMM_ACT_RELU, s));
+    else
+      ECG_TRY(ecg_linear_fwd(w.fused, P(params, P_FC0), P(params, P_FC0 + 1), w.h, B, D, H, ECGMM_ACT_RELU, nullptr, s));
+    const bool drop = d->training && d->dropout_p > 0.f;
+    if (drop) ECG_TRY(ecg_dropout_fwd(w.h, w.hd, w.mask, (long)B * H, d->dropout_p, d->seed, d->offset, s));
+    ECG_TRY(ecg_linear_fwd(drop ? w.hd : w.h, P(params, P_FC3), P(params, P_FC3 + 1), logits[3], B, H, NC, ECGMM_ACT_NONE,
+                           nullptr, s));
+    return ecg_varloss_finish(w.vscr, B, var_loss, s);
+  }
   for (int m = 0; m < 3; ++m) {
     const float* seg[3] = {raw[m], nullptr, nullptr};
     const int dims[3] = {d->dim[m], 0, 0};
@@ -163,6 +185,44 @@ extern "C" int ecgmm_head_backward(const ecgmm_head_desc* d, const float* const*
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "head bwd: workspace %zu < %zu", ws_bwd_bytes, q.bytes);
   const int B = d->B, D = d->dim[0] + d->dim[1] + d->dim[2], H = d->hidden, NC = d->num_classes;
   bool have[3] = {false, false, false};  // dfeat[m] holds something yet?
+
+  if (ecg_head_fused_ok(d->dim, B, H, NC)) {
+    const bool fusion = dlogits[3] != nullptr;
+    if (fusion) {
+      const bool drop = d->training && d->dropout_p > 0.f;
+      ECG_TRY(ecg_linear_bwd(dlogits[3], drop ? w.hd : w.h, P(params, P_FC3), q.dhd, G(grads, P_FC3), G(grads, P_FC3 + 1),
+                             B, H, NC, q.lin_scr, q.lin_bytes, s));
+      const float* dh = q.dhd;
+      if (drop) {
+        ECG_TRY(ecg_dropout_bwd(q.dhd, w.mask, q.dz, (long)B * H, d->dropout_p, s));
+        dh = q.dz;
+      }
+      ECG_TRY(ecg_act_bwd(dh, w.h, q.dz, (long)B * H, ECGMM_ACT_RELU, s));
+      if (ecg_dense16_ok(q.dz, P(params, P_FC0), q.dfused, B, D, H) && ecg_dense16_ok(w.fused, G(grads, P_FC0), q.dz, B, D, H)) {
+        ECG_TRY(ecg_dense16_dgrad(q.dz, P(params, P_FC0), q.dfused, B, D, H, s));
+        if (G(grads, P_FC0)) ECG_TRY(ecg_dense16_wgrad(q.dz, w.fused, G(grads, P_FC0), B, D, H, s));
+      } else {
+        ECG_TRY(ecg_linear_bwd(q.dz, w.fused, P(params, P_FC0), q.dfused, G(grads, P_FC0), nullptr, B, D, H, q.lin_scr,
+                               q.lin_bytes, s));
+      }
+    }
+    int hv[3], hc[3];
+    const float *ln_g[3], *cls_w[3], *dl[3];
+    float *g_ln[6], *g_cls[6];
+    for (int m = 0; m < 3; ++m) {
+      hc[m] = dlogits[m] != nullptr;
+      hv[m] = fusion || dvar != nullptr || hc[m];
+      ln_g[m] = P(params, P_LN + 2 * m); cls_w[m] = P(params, P_CLS + 2 * m); dl[m] = dlogits[m];
+      g_ln[2 * m] = G(grads, P_LN + 2 * m); g_ln[2 * m + 1] = G(grads, P_LN + 2 * m + 1);
+      g_cls[2 * m] = G(grads, P_CLS + 2 * m); g_cls[2 * m + 1] = G(grads, P_CLS + 2 * m + 1);
+    }
+    ECG_TRY(ecg_head_rows_bwd(raw, ln_g, cls_w, P(params, P_AW), P(params, P_ALN), w.feat, w.stat, w.statf,
+                              fusion ? q.dfused : nullptr, dl, dvar, w.vscr + 3 * (size_t)B, draw, hv, q.partial, d->dim, B,
+                              NC, s));
+    return ecg_head_finalize(q.partial, ecg_head_bwd_blocks(B), d->dim, NC, g_ln, g_cls, G(grads, P_AW), G(grads, P_ALN),
+                             G(grads, P_ALN + 1), P(params, P_AW), hv, hc, fusion ? 1 : 0, fusion ? q.dz : nullptr, B, H,
+                             fusion ? G(grads, P_FC0 + 1) : nullptr, s);
+  }
 
   if (dlogits[3]) {
     const bool drop = d->training && d->dropout_p > 0.f;

@@ -164,8 +164,9 @@ def test_dropout_statistics_and_backward():
     assert HF.dropout(x, 0.3, False) is x  # eval: identity
 
 
+@pytest.mark.parametrize("B", [24, 32, 256])   # 24: per-op launch plan; multiples of 16: fused row kernels + dense16 (head_fused.hip)
 @pytest.mark.parametrize("loss_kind", ["train_py", "all_heads", "branch_only"])
-def test_fused_head_plan_matches_modules_and_oracle(loss_kind):
+def test_fused_head_plan_matches_modules_and_oracle(loss_kind, B):
     """csrc/plan_head.hip (one native call per direction) == the module-by-module head == the oracle's head
     (PMB:326-354): all six outputs, every parameter gradient, the gradients handed to the encoders; and heads that are not
     in the loss (train.py:78 uses fusion_logits + var_loss only) keep grad None."""
@@ -183,7 +184,6 @@ def test_fused_head_plan_matches_modules_and_oracle(loss_kind):
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
         nets.append(n.to(DEV).train())
-    B = 24
     raws = [fill.hash_tensor((B, 256), 90 + i, 1.5) for i in range(3)]
     lab = torch.arange(B) % 2
 
@@ -233,6 +233,45 @@ def test_fused_head_plan_matches_modules_and_oracle(loss_kind):
     # fused == unfused to fp32 rounding
     for a, b in zip(results[0][0], results[1][0]):
         assert (a - b).abs().max() < 1e-6
+
+
+def test_fused_head_row_kernels_at_the_tabnet_variant_widths():
+    """multimodal.py's head (widths 512 / 128 / 32, fused 672 -> 128 -> 2): fused row kernels + dense16 kernels
+    (csrc/head_fused.hip, HM = 8 instantiation) == the module-by-module head, outputs and every gradient"""
+    from ecgmm.config import Config
+    from ecgmm.multimodal import ECGMultimodalModel
+    from oracle import fill
+    B = 48
+    raws = [fill.hash_tensor((B, d), 70 + i, 1.5) for i, d in enumerate((512, 128, 32))]
+    lab = dev(torch.arange(B) % 2)
+    res = []
+    sd = None
+    for fused in (True, False):
+        cfg = type("Cf", (Config,), {"device": DEV, "compute_dtype": "fp32", "fused_head": fused})
+        n = ECGMultimodalModel(cfg)
+        if sd is None:
+            sd = fill.hash_fill_module(n, "hw.").state_dict()
+        n.load_state_dict(sd)
+        for m in n.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        n = n.to(DEV).train()
+        rg = [dev(t).requires_grad_(True) for t in raws]
+        spec = n._head_spec()
+        assert (spec is not None) == fused
+        out = E.run_head(*rg, spec, n._head_params()) if fused else n._head_by_modules(*rg)
+        (HF.cross_entropy(out[3], lab) + HF.cross_entropy(out[0], lab) + 0.1 * out[4]).backward()
+        torch.cuda.synchronize()
+        res.append((out, rg, {k: p.grad for k, p in n.named_parameters() if "encoder" not in k}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert (a - b).abs().max() < 2e-5
+    for a, b in zip(res[0][1], res[1][1]):
+        assert rel_err(a.grad, b.grad) < 1e-4
+    for k, g in res[1][2].items():
+        if g is None:
+            assert res[0][2][k] is None, k
+        else:
+            assert res[0][2][k] is not None and rel_err(res[0][2][k], g) < 2e-4, k
 
 
 def test_cross_entropy_plus_is_ce_plus_weighted_extra():
