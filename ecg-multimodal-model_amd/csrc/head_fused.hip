@@ -45,41 +45,63 @@ struct HeadRows {
   float eps;
 };
 
-// HM = values per lane per modality (dims <= 64 HM), NCM = max classes
-template <int HM, int NCM>
+// H0, H1, H2 = values per lane of the three modalities (dim_m <= 64 H_m; arrays are sized for the largest, the unused
+// slots fold away after unrolling), NCM = max classes.
+// Every global load of the row is issued before the first dependent use (the row is a chain of ~20 reductions; with the
+// loads left where they are used, each phase paid its own L2/HBM latency: 30 us for 64 workgroups' worth of rows).
+template <int H0, int H1, int H2, int NCM>
 __global__ __launch_bounds__(256) void head_rows_fwd_kernel(HeadRows p) {
+  constexpr int HM = H0 > H1 ? (H0 > H2 ? H0 : H2) : (H1 > H2 ? H1 : H2);
+#define HMM(m) ((m) == 0 ? H0 : (m) == 1 ? H1 : H2)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   float sw[3];
   softmax3f(p.aw, sw);
   if (p.soft_w && blockIdx.x == 0 && threadIdx.x < 3) p.soft_w[threadIdx.x] = sw[threadIdx.x];
   if (row >= p.B) return;
+  float v[3][HM], lg[3][HM], lb[3][HM], cw[3][NCM][HM], cb[3][NCM], fgv[3][HM], fbv[3][HM];
+  {
+    int off = 0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int d = p.dim[m];
+#pragma unroll
+      for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
+        const int c = lane + 64 * k;
+        const bool ok = c < d;
+        v[m][k] = ok ? p.raw[m][(size_t)row * d + c] : 0.f;
+        lg[m][k] = ok ? p.ln_g[m][c] : 0.f;
+        lb[m][k] = ok ? p.ln_b[m][c] : 0.f;
+        fgv[m][k] = ok ? p.fg[off + c] : 0.f;
+        fbv[m][k] = ok ? p.fb[off + c] : 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NCM; ++cc) cw[m][cc][k] = (ok && cc < p.NC) ? p.cls_w[m][(size_t)cc * d + c] : 0.f;
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCM; ++cc) cb[m][cc] = cc < p.NC ? p.cls_b[m][cc] : 0.f;
+      off += d;
+    }
+  }
   float f[3][HM];
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     const int d = p.dim[m];
-    const float* src = p.raw[m] + (size_t)row * d;
-    float v[HM], s = 0.f;
+    float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
-      const int c = lane + 64 * k;
-      v[k] = c < d ? src[c] : 0.f;
-      s += v[k];
-    }
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) s += v[m][k];
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
-      const int c = lane + 64 * k;
-      const float dd = c < d ? v[k] - mean : 0.f;
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
+      const float dd = lane + 64 * k < d ? v[m][k] - mean : 0.f;
       q += dd * dd;
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)d + p.eps);
     float s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
       const int c = lane + 64 * k;
-      f[m][k] = c < d ? (v[k] - mean) * rstd * p.ln_g[m][c] + p.ln_b[m][c] : 0.f;
+      f[m][k] = c < d ? (v[m][k] - mean) * rstd * lg[m][k] + lb[m][k] : 0.f;
       if (c < d) p.feat[m][(size_t)row * d + c] = f[m][k];
       s2 += f[m][k];
     }
@@ -93,20 +115,16 @@ __global__ __launch_bounds__(256) void head_rows_fwd_kernel(HeadRows p) {
       if (c >= p.NC) break;
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < HM; ++k) {
-        const int col = lane + 64 * k;
-        if (col < d) t += f[m][k] * p.cls_w[m][(size_t)c * d + col];
-      }
+      for (int k = 0; k < HM; ++k) if (k < HMM(m)) t += f[m][k] * cw[m][c][k];
       t = wave_sum(t);
-      if (lane == 0) p.logits[m][(size_t)row * p.NC + c] = t + p.cls_b[m][c];
+      if (lane == 0) p.logits[m][(size_t)row * p.NC + c] = t + cb[m][c];
     }
     // unbiased variance of the feature row (rowvar_kernel)
     const float fmean = wave_sum(s2) / (float)d;
     float q2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
-      const int c = lane + 64 * k;
-      const float dd = c < d ? f[m][k] - fmean : 0.f;
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
+      const float dd = lane + 64 * k < d ? f[m][k] - fmean : 0.f;
       q2 += dd * dd;
     }
     q2 = wave_sum(q2);
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void head_rows_fwd_kernel(HeadRows p) {
 #pragma unroll
   for (int m = 0; m < 3; ++m)
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
       f[m][k] *= sw[m];   // (0 stays 0 beyond d_m)
       s += f[m][k];
     }
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256) void head_rows_fwd_kernel(HeadRows p) {
 #pragma unroll
   for (int m = 0; m < 3; ++m)
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
       const float dd = lane + 64 * k < p.dim[m] ? f[m][k] - mean : 0.f;
       q += dd * dd;
     }
@@ -135,9 +153,9 @@ __global__ __launch_bounds__(256) void head_rows_fwd_kernel(HeadRows p) {
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
 #pragma unroll
-    for (int k = 0; k < HM; ++k) {
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
       const int c = lane + 64 * k;
-      if (c < p.dim[m]) p.fused[(size_t)row * p.D + off + c] = (f[m][k] - mean) * rstd * p.fg[off + c] + p.fb[off + c];
+      if (c < p.dim[m]) p.fused[(size_t)row * p.D + off + c] = (f[m][k] - mean) * rstd * fgv[m][k] + fbv[m][k];
     }
     off += p.dim[m];
   }
@@ -168,8 +186,9 @@ __host__ __device__ inline int head_part_base(const int* dim, int D, int NC, int
   return o;
 }
 
-template <int HM, int NCM>
+template <int H0, int H1, int H2, int NCM>
 __global__ __launch_bounds__(256) void head_rows_bwd_kernel(HeadRowsBwd q) {
+  constexpr int HM = H0 > H1 ? (H0 > H2 ? H0 : H2) : (H1 > H2 ? H1 : H2);
   const HeadRows& p = q.f;
   extern __shared__ float shp[];   // [P]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -179,63 +198,72 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(HeadRowsBwd q) {
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
 #pragma unroll
-    for (int k = 0; k < HM; ++k) afg[m][k] = afb[m][k] = ag[m][k] = ab[m][k] = 0.f;
+    for (int k = 0; k < HM; ++k) if (k < HMM(m)) afg[m][k] = afb[m][k] = ag[m][k] = ab[m][k] = 0.f;
 #pragma unroll
     for (int c = 0; c < NCM; ++c) {
       acb[m][c] = 0.f;
 #pragma unroll
-      for (int k = 0; k < HM; ++k) aW[m][c][k] = 0.f;
+      for (int k = 0; k < HM; ++k) if (k < HMM(m)) aW[m][c][k] = 0.f;
     }
   }
   for (int row = blockIdx.x * 4 + wv; row < p.B; row += gridDim.x * 4) {
-    float ft[3][HM], df[3][HM];
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int k = 0; k < HM; ++k) {
-        const int c = lane + 64 * k;
-        ft[m][k] = c < p.dim[m] ? p.feat[m][(size_t)row * p.dim[m] + c] : 0.f;
-        df[m][k] = 0.f;
-      }
-    if (q.dfused) {   // LayerNorm(D) backward over the scaled concat, then the softmax(3) scaling
-      const float mean = p.statf[2 * row], rstd = p.statf[2 * row + 1];
-      float s1 = 0.f, s2 = 0.f;
+    // every load of the row first (see head_rows_fwd_kernel)
+    float ft[3][HM], df[3][HM], dfu[3][HM], fgv[3][HM], rw[3][HM], lg[3][HM], cw[3][NCM][HM], gl[3][NCM];
+    float mean_m[3], rstd_m[3];
+    const float mean_f = q.dfused ? p.statf[2 * row] : 0.f, rstd_f = q.dfused ? p.statf[2 * row + 1] : 0.f;
+    const float dvar = q.dvar ? q.dvar[0] : 0.f;
+    {
       int off = 0;
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
+        const int d = p.dim[m];
+        mean_m[m] = p.stat[m][2 * row];
+        rstd_m[m] = p.stat[m][2 * row + 1];
 #pragma unroll
-        for (int k = 0; k < HM; ++k) {
+        for (int cc = 0; cc < NCM; ++cc) gl[m][cc] = (q.dlog[m] && cc < p.NC) ? q.dlog[m][(size_t)row * p.NC + cc] : 0.f;
+#pragma unroll
+        for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
           const int c = lane + 64 * k;
-          if (c < p.dim[m]) {
-            const float xh = (ft[m][k] * sw[m] - mean) * rstd;
-            const float d = q.dfused[(size_t)row * p.D + off + c];
-            afg[m][k] += d * xh;
-            afb[m][k] += d;
-            const float dg = d * p.fg[off + c];
+          const bool ok = c < d;
+          ft[m][k] = ok ? p.feat[m][(size_t)row * d + c] : 0.f;
+          rw[m][k] = ok ? p.raw[m][(size_t)row * d + c] : 0.f;
+          lg[m][k] = ok ? p.ln_g[m][c] : 0.f;
+          dfu[m][k] = (ok && q.dfused) ? q.dfused[(size_t)row * p.D + off + c] : 0.f;
+          fgv[m][k] = (ok && q.dfused) ? p.fg[off + c] : 0.f;
+#pragma unroll
+          for (int cc = 0; cc < NCM; ++cc)
+            cw[m][cc][k] = (ok && q.dlog[m] && cc < p.NC) ? p.cls_w[m][(size_t)cc * d + c] : 0.f;
+          df[m][k] = 0.f;
+        }
+        off += d;
+      }
+    }
+    if (q.dfused) {   // LayerNorm(D) backward over the scaled concat, then the softmax(3) scaling
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int k = 0; k < HM; ++k) if (k < HMM(m))
+          if (lane + 64 * k < p.dim[m]) {
+            const float xh = (ft[m][k] * sw[m] - mean_f) * rstd_f;
+            afg[m][k] += dfu[m][k] * xh;
+            afb[m][k] += dfu[m][k];
+            const float dg = dfu[m][k] * fgv[m][k];
             s1 += dg;
             s2 += dg * xh;
           }
-        }
-        off += p.dim[m];
-      }
       s1 = wave_sum(s1) / (float)p.D;
       s2 = wave_sum(s2) / (float)p.D;
-      off = 0;
 #pragma unroll
-      for (int m = 0; m < 3; ++m) {
+      for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int k = 0; k < HM; ++k) {
-          const int c = lane + 64 * k;
-          if (c < p.dim[m]) {
-            const float xh = (ft[m][k] * sw[m] - mean) * rstd;
-            const float dg = q.dfused[(size_t)row * p.D + off + c] * p.fg[off + c];
-            const float dx = rstd * (dg - s1 - xh * s2);
+        for (int k = 0; k < HM; ++k) if (k < HMM(m))
+          if (lane + 64 * k < p.dim[m]) {
+            const float xh = (ft[m][k] * sw[m] - mean_f) * rstd_f;
+            const float dx = rstd_f * (dfu[m][k] * fgv[m][k] - s1 - xh * s2);
             aw3[m] += dx * ft[m][k];
             df[m][k] = dx * sw[m];
           }
-        }
-        off += p.dim[m];
-      }
     }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(HeadRowsBwd q) {
       if (!q.have[m]) {
         if (q.draw[m])
 #pragma unroll
-          for (int k = 0; k < HM; ++k) {
+          for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
             const int c = lane + 64 * k;
             if (c < d) q.draw[m][(size_t)row * d + c] = 0.f;
           }
@@ -252,40 +280,36 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(HeadRowsBwd q) {
       if (q.dvar) {   // varloss_bwd_kernel
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < HM; ++k) s += ft[m][k];
+        for (int k = 0; k < HM; ++k) if (k < HMM(m)) s += ft[m][k];
         const float fmean = wave_sum(s) / (float)d;
-        const float kk = q.dvar[0] * q.gs[m] * 2.f / ((float)(d - 1) * (float)p.B);
+        const float kk = dvar * q.gs[m] * 2.f / ((float)(d - 1) * (float)p.B);
 #pragma unroll
-        for (int k = 0; k < HM; ++k)
+        for (int k = 0; k < HM; ++k) if (k < HMM(m))
           if (lane + 64 * k < d) df[m][k] += kk * (ft[m][k] - fmean);
       }
       if (q.dlog[m]) {   // branch classifier: d feat += dlogits W, dW += dlogits^T feat, db += dlogits
 #pragma unroll
         for (int c = 0; c < NCM; ++c) {
           if (c >= p.NC) break;
-          const float gl = q.dlog[m][(size_t)row * p.NC + c];
-          acb[m][c] += gl;
+          acb[m][c] += gl[m][c];
 #pragma unroll
-          for (int k = 0; k < HM; ++k) {
-            const int col = lane + 64 * k;
-            if (col < d) {
-              aW[m][c][k] += gl * ft[m][k];
-              df[m][k] += gl * p.cls_w[m][(size_t)c * d + col];
+          for (int k = 0; k < HM; ++k) if (k < HMM(m))
+            if (lane + 64 * k < d) {
+              aW[m][c][k] += gl[m][c] * ft[m][k];
+              df[m][k] += gl[m][c] * cw[m][c][k];
             }
-          }
         }
       }
       // LayerNorm_m backward
-      const float mean = p.stat[m][2 * row], rstd = p.stat[m][2 * row + 1];
+      const float mean = mean_m[m], rstd = rstd_m[m];
       float xh[HM], dg[HM], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < HM; ++k) {
-        const int c = lane + 64 * k;
-        if (c < d) {
-          xh[k] = (p.raw[m][(size_t)row * d + c] - mean) * rstd;
+      for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
+        if (lane + 64 * k < d) {
+          xh[k] = (rw[m][k] - mean) * rstd;
           ag[m][k] += df[m][k] * xh[k];
           ab[m][k] += df[m][k];
-          dg[k] = df[m][k] * p.ln_g[m][c];
+          dg[k] = df[m][k] * lg[m][k];
           s1 += dg[k];
           s2 += dg[k] * xh[k];
         } else {
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(HeadRowsBwd q) {
       s2 = wave_sum(s2) / (float)d;
       if (q.draw[m])
 #pragma unroll
-        for (int k = 0; k < HM; ++k) {
+        for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
           const int c = lane + 64 * k;
           if (c < d) q.draw[m][(size_t)row * d + c] = rstd * (dg[k] - s1 - xh[k] * s2);
         }
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(256) void head_rows_bwd_kernel(HeadRowsBwd q) {
       for (int m = 0; m < 3; ++m) {
         const int d = p.dim[m], base = head_part_base(p.dim, p.D, p.NC, m);
 #pragma unroll
-        for (int k = 0; k < HM; ++k) {
+        for (int k = 0; k < HM; ++k) if (k < HMM(m)) {
           const int c = lane + 64 * k;
           if (c < d) {
             float* t = shp;
@@ -369,33 +393,52 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(HeadFinalize h) {
     for (int s = 0; s < h.nseg; ++s)
       if (o >= h.seg[s].off && o < h.seg[s].off + h.seg[s].n) dst = h.seg[s].dst ? h.seg[s].dst + (o - h.seg[s].off) : nullptr;
     if (dst) {
-      float s0 = 0.f, s1 = 0.f;
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight; fixed fold order
       int r = 0;
-      for (; r + 1 < h.rows; r += 2) {
-        s0 += h.partial[(size_t)r * h.P + o];
-        s1 += h.partial[(size_t)(r + 1) * h.P + o];
-      }
-      if (r < h.rows) s0 += h.partial[(size_t)r * h.P + o];
-      *dst = s0 + s1;
+      for (; r + 8 <= h.rows; r += 8)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += h.partial[(size_t)(r + u) * h.P + o];
+      for (; r < h.rows; ++r) a[0] += h.partial[(size_t)r * h.P + o];
+      *dst = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
   } else if (o < h.P + h.col_n && h.col_src) {
     const int j = o - h.P;
-    float s0 = 0.f, s1 = 0.f;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int r = 0;
-    for (; r + 1 < h.col_rows; r += 2) {
-      s0 += h.col_src[(size_t)r * h.col_n + j];
-      s1 += h.col_src[(size_t)(r + 1) * h.col_n + j];
-    }
-    if (r < h.col_rows) s0 += h.col_src[(size_t)r * h.col_n + j];
-    h.col_dst[j] = s0 + s1;
+    for (; r + 8 <= h.col_rows; r += 8)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += h.col_src[(size_t)(r + u) * h.col_n + j];
+    for (; r < h.col_rows; ++r) a[0] += h.col_src[(size_t)r * h.col_n + j];
+    h.col_dst[j] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && h.daw) {
+  if (blockIdx.x == 0 && threadIdx.x < 64 && h.daw) {   // one wave: rows across lanes, butterfly, softmax(3) backward
     float dw[3] = {0.f, 0.f, 0.f}, w[3];
-    for (int r = 0; r < h.rows; ++r)
+    for (int r = threadIdx.x; r < h.rows; r += 64)
+#pragma unroll
       for (int m = 0; m < 3; ++m) dw[m] += h.partial[(size_t)r * h.P + h.aw_off + m];
-    softmax3f(h.aw, w);
-    const float dot = w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2];
-    for (int m = 0; m < 3; ++m) h.daw[m] = w[m] * (dw[m] - dot);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) dw[m] = wave_sum(dw[m]);
+    if (threadIdx.x == 0) {
+      softmax3f(h.aw, w);
+      const float dot = w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2];
+      for (int m = 0; m < 3; ++m) h.daw[m] = w[m] * (dw[m] - dot);
+    }
+  }
+}
+
+// dz[b][h] = relu'(h_act) * dropout'(mask) * sum_c dlogits[b][c] W[c][h]: the input gradient of Linear(H -> NC) pushed through
+// Dropout and ReLU in one elementwise pass (linear_dgrad_kernel + dropout_bwd_kernel + act_bwd_kernel)
+__global__ __launch_bounds__(256) void fc_dgrad_drop_relu_kernel(const float* __restrict__ dlog, const float* __restrict__ w,
+                                                                  const unsigned char* __restrict__ mask,
+                                                                  const float* __restrict__ hact, float* __restrict__ dz,
+                                                                  int B, int H, int NC, float keep_scale) {
+  const long total = (long)B * H;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int b = (int)(e / H), j = (int)(e % H);
+    float s = 0.f;
+    for (int c = 0; c < NC; ++c) s += dlog[(size_t)b * NC + c] * w[(size_t)c * H + j];
+    if (mask) s = mask[e] ? s * keep_scale : 0.f;
+    dz[e] = hact[e] > 0.f ? s : 0.f;
   }
 }
 
@@ -488,10 +531,12 @@ int ecg_head_rows_fwd(const float* const* raw, const float* const* ln_g, const f
   }
   p.aw = aw; p.fg = fg; p.fb = fb; p.rowvar = rowvar; p.fused = fused; p.statf = statf; p.soft_w = soft_w;
   p.B = B; p.D = dim[0] + dim[1] + dim[2]; p.NC = NC; p.eps = eps;
-  const int mx = dim[0] > dim[1] ? (dim[0] > dim[2] ? dim[0] : dim[2]) : (dim[1] > dim[2] ? dim[1] : dim[2]);
   const dim3 grid((B + 3) / 4), block(256);
-  if (mx <= 256) hipLaunchKernelGGL((head_rows_fwd_kernel<4, 4>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((head_rows_fwd_kernel<8, 4>), grid, block, 0, s, p);
+  const bool pmb = dim[0] <= 256 && dim[1] <= 256 && dim[2] <= 256;    // multimodal_paper_modal_balance.py: 3 x 256
+  const bool tab = dim[0] <= 512 && dim[1] <= 128 && dim[2] <= 64;      // multimodal.py: 512 / 128 / 32
+  if (pmb && NC <= 2) hipLaunchKernelGGL((head_rows_fwd_kernel<4, 4, 4, 2>), grid, block, 0, s, p);
+  else if (tab && NC <= 2) hipLaunchKernelGGL((head_rows_fwd_kernel<8, 2, 1, 2>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((head_rows_fwd_kernel<8, 8, 8, 4>), grid, block, 0, s, p);
   ECG_CHECK_LAUNCH("head_rows_fwd");
   return 0;
 }
@@ -514,23 +559,13 @@ int ecg_head_rows_bwd(const float* const* raw, const float* const* ln_g, const f
   p.B = B; p.D = dim[0] + dim[1] + dim[2]; p.NC = NC;
   q.dfused = dfused; q.dvar = dvar; q.gs = gs; q.partial = partial;
   q.P = ecg_head_partial_floats(dim, NC);
-  const int mx = dim[0] > dim[1] ? (dim[0] > dim[2] ? dim[0] : dim[2]) : (dim[1] > dim[2] ? dim[1] : dim[2]);
   const dim3 grid(ecg_head_bwd_blocks(B)), block(256);
-  const size_t lds = (size_t)q.P * sizeof(float);
-  static bool attr4 = false, attr8 = false;
-  if (mx <= 256) {
-    if (!attr4) {
-      (void)hipFuncSetAttribute((const void*)head_rows_bwd_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      attr4 = true;
-    }
-    hipLaunchKernelGGL((head_rows_bwd_kernel<4, 4>), grid, block, lds, s, q);
-  } else {
-    if (!attr8) {
-      (void)hipFuncSetAttribute((const void*)head_rows_bwd_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      attr8 = true;
-    }
-    hipLaunchKernelGGL((head_rows_bwd_kernel<8, 4>), grid, block, lds, s, q);
-  }
+  const size_t lds = (size_t)q.P * sizeof(float);   // 18.5 KB at 3 x 256 features, 2 classes; <= 64 KB for every shape ecg_head_fused_ok admits
+  const bool pmb = dim[0] <= 256 && dim[1] <= 256 && dim[2] <= 256;
+  const bool tab = dim[0] <= 512 && dim[1] <= 128 && dim[2] <= 64;
+  if (pmb && NC <= 2) hipLaunchKernelGGL((head_rows_bwd_kernel<4, 4, 4, 2>), grid, block, lds, s, q);
+  else if (tab && NC <= 2) hipLaunchKernelGGL((head_rows_bwd_kernel<8, 2, 1, 2>), grid, block, lds, s, q);
+  else hipLaunchKernelGGL((head_rows_bwd_kernel<8, 8, 8, 4>), grid, block, lds, s, q);
   ECG_CHECK_LAUNCH("head_rows_bwd");
   return 0;
 }
@@ -566,6 +601,17 @@ int ecg_head_finalize(const float* partial, int rows, const int* dim, int NC, fl
   const int total = h.P + (h.col_src ? H : 0);
   hipLaunchKernelGGL(head_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, h);
   ECG_CHECK_LAUNCH("head_finalize");
+  return 0;
+}
+
+int ecg_fc_dgrad_drop_relu(const float* dlog, const float* w, const unsigned char* mask, const float* hact, float* dz,
+                           int B, int H, int NC, float dropout_p, hipStream_t s) {
+  const long total = (long)B * H;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(fc_dgrad_drop_relu_kernel, dim3(grid), dim3(256), 0, s, dlog, w, mask, hact, dz, B, H, NC,
+                     1.f / (1.f - dropout_p));
+  ECG_CHECK_LAUNCH("fc_dgrad_drop_relu");
   return 0;
 }
 

@@ -127,6 +127,8 @@ int ecg_dense16_fwd(const float* x, const float* w, const float* bias, float* y,
                     hipStream_t s);
 int ecg_dense16_dgrad(const float* dy, const float* w, float* dx, int B, int In, int Out, hipStream_t s);
 int ecg_dense16_wgrad(const float* dy, const float* x, float* dw, int B, int In, int Out, hipStream_t s);
+int ecg_fc_dgrad_drop_relu(const float* dlog, const float* w, const unsigned char* mask, const float* hact, float* dz,
+                           int B, int H, int NC, float dropout_p, hipStream_t s);
 int ecg_varloss_finish(float* scratch, int B, float* loss, hipStream_t s);
 int ecg_varloss_fwd(const float* f0, const float* f1, const float* f2, int B, int D0, int D1, int D2, float* loss,
                     float* scratch, hipStream_t s);

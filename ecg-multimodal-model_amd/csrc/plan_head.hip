@@ -190,14 +190,11 @@ extern "C" int ecgmm_head_backward(const ecgmm_head_desc* d, const float* const*
     const bool fusion = dlogits[3] != nullptr;
     if (fusion) {
       const bool drop = d->training && d->dropout_p > 0.f;
-      ECG_TRY(ecg_linear_bwd(dlogits[3], drop ? w.hd : w.h, P(params, P_FC3), q.dhd, G(grads, P_FC3), G(grads, P_FC3 + 1),
+      // fusion_classifier.3: weight / bias gradients; its input gradient goes through Dropout and ReLU in one pass
+      ECG_TRY(ecg_linear_bwd(dlogits[3], drop ? w.hd : w.h, P(params, P_FC3), nullptr, G(grads, P_FC3), G(grads, P_FC3 + 1),
                              B, H, NC, q.lin_scr, q.lin_bytes, s));
-      const float* dh = q.dhd;
-      if (drop) {
-        ECG_TRY(ecg_dropout_bwd(q.dhd, w.mask, q.dz, (long)B * H, d->dropout_p, s));
-        dh = q.dz;
-      }
-      ECG_TRY(ecg_act_bwd(dh, w.h, q.dz, (long)B * H, ECGMM_ACT_RELU, s));
+      ECG_TRY(ecg_fc_dgrad_drop_relu(dlogits[3], P(params, P_FC3), drop ? w.mask : nullptr, w.h, q.dz, B, H, NC,
+                                     d->dropout_p, s));
       if (ecg_dense16_ok(q.dz, P(params, P_FC0), q.dfused, B, D, H) && ecg_dense16_ok(w.fused, G(grads, P_FC0), q.dz, B, D, H)) {
         ECG_TRY(ecg_dense16_dgrad(q.dz, P(params, P_FC0), q.dfused, B, D, H, s));
         if (G(grads, P_FC0)) ECG_TRY(ecg_dense16_wgrad(q.dz, w.fused, G(grads, P_FC0), B, D, H, s));

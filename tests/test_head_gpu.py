@@ -235,19 +235,26 @@ def test_fused_head_plan_matches_modules_and_oracle(loss_kind, B):
         assert (a - b).abs().max() < 1e-6
 
 
-def test_fused_head_row_kernels_at_the_tabnet_variant_widths():
-    """multimodal.py's head (widths 512 / 128 / 32, fused 672 -> 128 -> 2): fused row kernels + dense16 kernels
-    (csrc/head_fused.hip, HM = 8 instantiation) == the module-by-module head, outputs and every gradient"""
+@pytest.mark.parametrize("variant", ["tabnet_512_128_32", "generic_320x3_3classes"])
+def test_fused_head_row_kernels_at_other_widths(variant):
+    """multimodal.py's head (widths 512 / 128 / 32, fused 672 -> 128 -> 2) and a width / class count outside both
+    reference models: fused row kernels + dense16 kernels (csrc/head_fused.hip, its <8,2,1,2> and generic
+    instantiations) == the module-by-module head, outputs and every gradient"""
     from ecgmm.config import Config
-    from ecgmm.multimodal import ECGMultimodalModel
     from oracle import fill
+    if variant.startswith("tabnet"):
+        from ecgmm.multimodal import ECGMultimodalModel
+        dims, extra, nc = (512, 128, 32), {}, 2
+    else:
+        from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+        dims, extra, nc = (320, 320, 320), {"modal_dim": 320, "num_classes": 3, "clinical_input_dim": 16}, 3
     B = 48
-    raws = [fill.hash_tensor((B, d), 70 + i, 1.5) for i, d in enumerate((512, 128, 32))]
-    lab = dev(torch.arange(B) % 2)
+    raws = [fill.hash_tensor((B, d), 70 + i, 1.5) for i, d in enumerate(dims)]
+    lab = dev(torch.arange(B) % nc)
     res = []
     sd = None
     for fused in (True, False):
-        cfg = type("Cf", (Config,), {"device": DEV, "compute_dtype": "fp32", "fused_head": fused})
+        cfg = type("Cf", (Config,), dict({"device": DEV, "compute_dtype": "fp32", "fused_head": fused}, **extra))
         n = ECGMultimodalModel(cfg)
         if sd is None:
             sd = fill.hash_fill_module(n, "hw.").state_dict()
