@@ -538,6 +538,13 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       };
       auto stores = [&](auto h_tag) {
         constexpr int h = decltype(h_tag)::value;
+#if defined(HALO_ABL) && HALO_ABL == 6   // diagnostic 6: no output stores (values kept alive)
+#pragma unroll
+        for (int ap = 0; ap < TA; ++ap)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) asm volatile("" ::"v"(oq[h][ap][bb]));
+        return;
+#endif
 #pragma unroll
         for (int ap = 0; ap < TA; ++ap)
 #pragma unroll
@@ -564,7 +571,11 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
         compute(H1{});
         stores(H1{});
       }
+#if defined(HALO_ABL) && HALO_ABL == 7   // diagnostic 7: no statistics reduction
+      if (false) {
+#else
       if ((MODE == 0 && p.stats) || (MODE == 1 && red)) {
+#endif
         // per-channel partial sums of this wave's 64 pixels: 16-lane DPP reduction, then either a row of the per-64-pixel
         // layout (what conv_igemm writes: forward only), or -- wg_rows -- added to this wave's LDS accumulators (only this
         // wave's fr == 0 lanes touch its [pixel quarter][channel] slots: plain read-modify-write, fixed order, reproducible)
@@ -734,12 +745,17 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
   int wg = 0;
   const bool wide = p.Cd > 64;
   int rc;
+  // MODE 2 = input gradient WITHOUT the fused BatchNorm-backward reduction compiled in: the reduction's operand registers
+  // push the BN = 128 instantiation over its 256-VGPR budget (396 B of scratch per lane) whether or not a launch uses it --
+  // 13 us of a 88 us layer-2 launch (tools/halo_abl.sh, ablation 7)
   if (g.R == 3) {
     if (mode == 0) rc = wide ? launch_halo<128, 9, 0>(p, &wg, stream) : launch_halo<64, 9, 0>(p, &wg, stream);
-    else rc = wide ? launch_halo<128, 9, 1>(p, &wg, stream) : launch_halo<64, 9, 1>(p, &wg, stream);
+    else if (p.red_y) rc = wide ? launch_halo<128, 9, 1>(p, &wg, stream) : launch_halo<64, 9, 1>(p, &wg, stream);
+    else rc = wide ? launch_halo<128, 9, 2>(p, &wg, stream) : launch_halo<64, 9, 2>(p, &wg, stream);
   } else {
     if (mode == 0) rc = wide ? launch_halo<128, 3, 0>(p, &wg, stream) : launch_halo<64, 3, 0>(p, &wg, stream);
-    else rc = wide ? launch_halo<128, 3, 1>(p, &wg, stream) : launch_halo<64, 3, 1>(p, &wg, stream);
+    else if (p.red_y) rc = wide ? launch_halo<128, 3, 1>(p, &wg, stream) : launch_halo<64, 3, 1>(p, &wg, stream);
+    else rc = wide ? launch_halo<128, 3, 2>(p, &wg, stream) : launch_halo<64, 3, 2>(p, &wg, stream);
   }
   if (epi) {
     epi->stats_rows = p.wg_rows ? wg : 2 * ceil_div(p.M, 128);
