@@ -106,7 +106,10 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   using C = HaloCfg<BN>;
   constexpr int TP = 4;         // 16-pixel tiles per wave (64 pixels)
   constexpr int TC = BN / 32;   // 16-channel tiles per wave
-  constexpr int HPS = RS == 9 ? 1 : C::NPW_MAX;  // halo pieces a wave issues per step (3-tap filters: all in the slice's first step)
+#ifndef HALO_HPS9
+#define HALO_HPS9 1   // (all of a slice's halo pieces in its first step, as the 3-tap filters do: 1-2 % slower on layers 2-4)
+#endif
+  constexpr int HPS = RS == 9 ? HALO_HPS9 : C::NPW_MAX;  // halo pieces a wave issues per step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -334,6 +337,9 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       else if (outstanding == 10) wait_vmcnt<10>();
       else if (outstanding == 11) wait_vmcnt<11>();
       else if (outstanding == 12) wait_vmcnt<12>();
+      else if (outstanding == 13) wait_vmcnt<13>();
+      else if (outstanding == 14) wait_vmcnt<14>();
+      else if (outstanding == 15) wait_vmcnt<15>();
       else wait_vmcnt<0>();
       wait_lds();
 #if !(defined(HALO_ABL) && HALO_ABL == 5)   // diagnostic 5: no per-step barrier
@@ -697,11 +703,11 @@ bool ecg_conv_halo_ok(int dtype, int mode, const ConvGeom& g) {
   if (hrows > (Cd > 64 ? HaloCfg<128>::HCAP : HaloCfg<64>::HCAP)) return false;
   if ((double)M * Cs * 2.0 > 2.0e9 || (double)M * Cd * 2.0 > 8.0e9) return false;
   if (g_halo_enabled == 2) return true;
-  // Where it pays (B = 256 layer shapes, same-call A/B against conv_igemm, profiles/r02_conv_bench_layers.txt): every 3x3
-  // layer (+5...+18 %) and the 1-D encoder's last stage.  The short 1-D reductions (64-128 input channels x 3 taps = 3-6
-  // K steps per tile) do not amortise the per-tile prologue / epilogue of the one resident workgroup: conv_igemm's two
-  // independent workgroups per CU are faster or equal there.
-  return g.R == 3 || Cs >= 256;
+  // Where it pays (B = 256 / 512 layer shapes, same-call A/B against conv_igemm, profiles/r02_conv_bench_layers.txt and
+  // tools/halo_1d.sh): every 3x3 layer (+5...+18 %) and the 1-D encoder's 128- and 256-channel stages (+7...+20 %).  The
+  // 64-channel 1-D layer (3 K steps per tile) does not amortise the per-tile prologue / epilogue of the one resident
+  // workgroup: conv_igemm's two independent workgroups per CU are 8 % faster there.
+  return g.R == 3 || Cs >= 128;
 }
 
 // partial rows a halo launch with ConvEpi.wg_rows writes: one per workgroup of a channel tile
