@@ -140,10 +140,13 @@ struct BnActParams {
   int C, rows_per_sample, relu;
 };
 
+#ifndef BN_ACT_THREADS
+#define BN_ACT_THREADS 1024
+#endif
 template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void bn_act_kernel(BnActParams p) {
+__global__ __launch_bounds__(BN_ACT_THREADS) void bn_act_kernel(BnActParams p) {
   constexpr int VEC = Elem<T>::VEC;
-  const int cpr = p.C / VEC, rpi = EW_THREADS / cpr;
+  const int cpr = p.C / VEC, rpi = BN_ACT_THREADS / cpr;
   const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
   const int c0 = chunk * VEC;
   float sc[VEC], sh[VEC], rs[VEC], rb[VEC];
@@ -972,9 +975,12 @@ int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, con
   p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
-  int grid = ew_grid(M, (EW_THREADS / (C / vec)) * 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, stream, p),
-             hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, stream, p), "bn_act");
+  // (1024-thread blocks, one per CU, each walking rows with a grid stride -- the launch shape of bn_bwd_kernel, which
+  // reaches 5.3 TB/s; 256-thread blocks x 4096 reached 4.3: 0.74 ms per step for the 22 launches)
+  int grid = ew_grid(M, (BN_ACT_THREADS / (C / vec)) * 4);
+  if (grid > 256) grid = 256;   // (sweep 128 / 256 / 384 / 512 blocks: 0.72 / 0.59 / 0.68 / 0.66 ms per step for the 22 launches)
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(BN_ACT_THREADS), 0, stream, p),
+             hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(BN_ACT_THREADS), 0, stream, p), "bn_act");
   ECG_CHECK_LAUNCH("bn_act");
   return 0;
 }
