@@ -735,7 +735,22 @@ __global__ __launch_bounds__(EW_THREADS) void sample_reduce_kernel(const T* __re
     sc[j] = (SEGATE || coef) ? coef[c0 + j] : 1.f;
     sf[j] = (SEGATE || coef) ? coef[C + c0 + j] : 0.f;
   }
-  for (int r = slice; r < R; r += nsl) {
+  int r = slice;
+  if (!SEGATE) {   // four rows in flight per thread (one load per iteration ran at 3.3 TB/s)
+    for (; r + 3 * nsl < R; r += 4 * nsl) {
+      u32x4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = ld16(x + ((size_t)n * R + r + u * nsl) * C + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[VEC];
+        unpack16<T>(q[u], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+      }
+    }
+  }
+  for (; r < R; r += nsl) {
     const size_t o = ((size_t)n * R + r) * C + c0;
     float f[VEC];
     unpack16<T>(ld16(x + o), f);
@@ -773,6 +788,22 @@ __global__ void bcast_rows_kernel(const float* __restrict__ v, T* __restrict__ o
     int c = (int)(i % C);
     long n = i / ((long)R * C);
     Elem<T>::st(out + i, v[n * C + c] * scale);
+  }
+}
+
+// the same with 16-byte stores: thread = (16-B channel chunk, row slice), one block per CU walking the rows
+template <typename T>
+__global__ __launch_bounds__(1024) void bcast_rows_vec_kernel(const float* __restrict__ v, T* __restrict__ out, long M,
+                                                              int R, int C, float scale) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cpr = C / VEC, rpi = 1024 / cpr;
+  const int c0 = (threadIdx.x % cpr) * VEC, r0 = threadIdx.x / cpr;
+  for (long r = (long)blockIdx.x * rpi + r0; r < M; r += (long)gridDim.x * rpi) {
+    const float* src = v + (r / R) * C + c0;
+    float f[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = src[j] * scale;
+    st16(out + r * C + c0, pack16<T>(f));
   }
 }
 
@@ -1169,6 +1200,18 @@ int ecg_avgpool(int dtype, const void* x, float* out, int N, int R, int C, const
 
 int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, float scale, hipStream_t stream) {
   long total = (long)N * R * C;
+  const int vecw = dtype == ECGMM_BF16 ? 8 : 4;
+  if (C % vecw == 0 && C / vecw <= 1024 && 1024 % (C / vecw) == 0 && ((uintptr_t)out & 15) == 0) {
+    const long M = (long)N * R;
+    int g = ew_grid(M, (1024 / (C / vecw)) * 4);
+    if (g > 256) g = 256;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bcast_rows_vec_kernel<bf16_t>, dim3(g), dim3(1024), 0, stream, v, (bf16_t*)out, M, R, C, scale),
+               hipLaunchKernelGGL(bcast_rows_vec_kernel<float>, dim3(g), dim3(1024), 0, stream, v, (float*)out, M, R, C, scale),
+               "bcast_rows");
+    ECG_CHECK_LAUNCH("bcast_rows_vec");
+    return 0;
+  }
   int grid = ew_grid(total, 256);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bcast_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, v, (bf16_t*)out, total, R,
