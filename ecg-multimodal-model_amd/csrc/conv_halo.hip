@@ -666,7 +666,9 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   HaloParams q = p;
   q.ntm = p.M / HBM_;
   q.ntn = p.Cd / BN;
-  const int cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
+  static const int cu_cap = [] { const char* e = getenv("ECGMM_HALO_CUS"); return e ? atoi(e) : 1 << 20; }();
+  int cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
+  if (cus > cu_cap) cus = cu_cap;
   // persistent: one workgroup per CU; Gk workgroups per channel tile (each walks pixel tiles k, k + Gk, ...)
   int Gk = cus / q.ntn;
   if (Gk > q.ntm) Gk = q.ntm;

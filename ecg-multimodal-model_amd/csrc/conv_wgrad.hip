@@ -750,11 +750,19 @@ int launch_wgrad_ring(const WgradRingParams& p, dim3 grid, hipStream_t stream) {
   return 0;
 }
 
+bool g_wgrad_narrow = false;
 int pick_nsplit(const ConvGeom& g, int kp, int groups) {
   long M = (long)g.N * g.OH * g.OW;
   int tiles = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
   int steps = ceil_div(M, kp);
-  int want = ceil_div(512 / groups, tiles);  // one resident round: 8 waves per CU (register-limited)
+  // One resident round.  Alone on the GPU a launch wants every CU (512 four-wave slots); on the weight-gradient SIDE
+  // stream it runs beside the critical path's dgrad -> BatchNorm chain, and -- an 8-wave, 144 KB-LDS workgroup shares
+  // its CU with nothing -- every CU it holds is one the chain waits for.  Narrow (half the CUs, twice as long) the step is
+  // 0.2 ms faster: sweep 512 / 384 / 256 / 192 / 128 slots = 7.39 / 7.24 / 7.18 / 7.21 / 7.82 ms per step, and the slabs
+  // shrink with the split count.  ECGMM_WGRAD_WGS overrides.
+  static const int slots_env = [] { const char* e = getenv("ECGMM_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+  const int slots = slots_env > 0 ? slots_env : (g_wgrad_narrow ? 256 : 512);
+  int want = ceil_div(slots / groups, tiles);
   int ns = want < 1 ? 1 : want;
   if (ns > steps) ns = steps;
   if (ns > 512) ns = 512;
@@ -769,7 +777,13 @@ extern "C" int ecgmm_conv_wgrad_ring_enable(int on) {
   return 0;
 }
 
+// narrow = the caller runs its weight gradients on a side stream beside other work (see pick_nsplit)
+void ecg_conv_wgrad_narrow(bool narrow) { g_wgrad_narrow = narrow; }
+
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g) {
+  const bool keep = g_wgrad_narrow;
+  g_wgrad_narrow = false;   // (upper bound over both settings)
+  struct Restore { bool v; ~Restore() { g_wgrad_narrow = v; } } restore{keep};
   int ns = pick_nsplit(g, dtype == ECGMM_BF16 ? 32 : 16, 1);   // (upper bound over the kernel variants)
   return (size_t)ns * g.R * g.S * g.Cout * g.Cin * sizeof(float);
 }

@@ -346,6 +346,9 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   const int dt = r.d.dtype, N = r.d.N;
   ECG_TRY(side_init());
   const bool side = g_side.enabled;
+  // weight gradients of this call run beside the dgrad chain: narrow launches (conv_wgrad.hip, pick_nsplit)
+  ecg_conv_wgrad_narrow(side);
+  struct NarrowOff { ~NarrowOff() { ecg_conv_wgrad_narrow(false); } } narrow_off;
   hipStream_t ws = side ? g_side.s : s;  // stream of the weight-gradient kernels
 
   for (int st = stage_begin; st < stage_end; ++st) {

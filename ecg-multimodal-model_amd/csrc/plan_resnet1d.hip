@@ -308,6 +308,9 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
   const int dt = r.d.dtype, N = r.d.N, cin = r.d.cin;
   ECG_TRY(g_side1.init());
   const bool side = g_side1.enabled;
+  // weight gradients of this call run beside the dgrad chain: narrow launches (conv_wgrad.hip, pick_nsplit)
+  ecg_conv_wgrad_narrow(side);
+  struct NarrowOff { ~NarrowOff() { ecg_conv_wgrad_narrow(false); } } narrow_off;
   hipStream_t wst = side ? g_side1.s : s;  // stream of the weight-gradient kernels
 
   for (int st = stage_begin; st < stage_end; ++st) {

@@ -57,9 +57,17 @@ def test_full_size_step_is_bitwise_deterministic_and_schedule_independent():
     L.lib().ecgmm_side_wgrad(1)
     (l0, y0, g0), (l1, y1, g1), (l2, y2, g2) = runs
     assert l0 == l1 == l2 and torch.equal(y0, y1) and torch.equal(y0, y2)
-    for k in g0:                                  # concurrent streams vs one stream: identical bits
+    for k in g0:                                  # run to run: identical bits
         assert torch.equal(g0[k], g1[k]), k
-        assert torch.equal(g0[k], g2[k]), k
+    # Concurrent streams vs one stream: the forward, every activation gradient and every per-channel gradient are
+    # identical bits (pure scheduling).  The split-K weight gradients are launched NARROW (half the CUs, half the splits)
+    # when they run on the side stream and full-width when they have the GPU to themselves (conv_wgrad.hip,
+    # pick_nsplit): same products, another fp32 summation order.
+    for k in g0:
+        if g0[k].ndim >= 2:
+            assert (g0[k] - g2[k]).norm() <= 1e-5 * g2[k].norm() + 1e-12, k
+        else:
+            assert torch.equal(g0[k], g2[k]), k
     assert all(torch.isfinite(v).all() for v in g0.values())
 
 
