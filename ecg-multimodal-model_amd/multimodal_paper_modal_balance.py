@@ -110,6 +110,10 @@ class ResNet1D_SE(nn.Module):
         return E.run_plan(x, spec, params)
 
 
+import os as _os
+_OVERLAP_ENV = _os.environ.get("ECGMM_OVERLAP_ENCODERS", "1") != "0"   # A/B switch: 0 = the three encoders on one stream
+
+
 class ECGMultimodalModel(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -196,7 +200,7 @@ class ECGMultimodalModel(nn.Module):
 
     def forward(self, image, ecg_signal, clinical):
         ecg_signal = ecg_signal.unsqueeze(1)
-        if image.is_cuda and getattr(self.config, "overlap_encoders", True):
+        if image.is_cuda and getattr(self.config, "overlap_encoders", True) and _OVERLAP_ENV:
             # The three encoders are independent until the fusion: run the (small-kernel) signal and
             # clinical branches on a side HIP stream underneath the image encoder's launches.  autograd
             # replays each backward node on the stream its forward ran on, so the backward overlaps too.
