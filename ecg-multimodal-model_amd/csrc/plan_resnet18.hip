@@ -87,6 +87,7 @@ struct FwdWs {
   } b[8];
   float* pooled;
   float* stats;  // transient partial-sum rows (largest layer)
+  float* stats_d;  // the same for the downsample convolutions (they run on the side stream beside conv1 / conv2)
   size_t bytes;
 };
 
@@ -101,6 +102,7 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
   w.idx0 = a.take<unsigned char>((size_t)N * r.H2 * r.W2 * 64);
   size_t max_rows_c = (size_t)ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7) * 2 * 64;
   max_rows_c += (size_t)ECG_TAIL_ROWS * 2 * 64;
+  size_t max_rows_d = 64;
   for (int i = 0; i < 8; ++i) {
     const BlockCfg& k = r.blk[i];
     FwdWs::B& b = w.b[i];
@@ -126,9 +128,11 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
     }
     size_t rows_c = (size_t)(ecg_conv_stats_rows((long)N * k.hout * k.wout) + ECG_TAIL_ROWS) * 2 * k.cout;
     if (rows_c > max_rows_c) max_rows_c = rows_c;
+    if (k.down && rows_c > max_rows_d) max_rows_d = rows_c;
   }
   w.pooled = a.take<float>((size_t)N * 512);
   w.stats = a.take<float>(max_rows_c);
+  w.stats_d = a.take<float>(max_rows_d);
   w.bytes = align_up(a.off, 256);
 }
 
@@ -273,6 +277,9 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   if (!ws || ws_bytes < w.bytes) ECG_FAIL(ECGMM_ERR_WORKSPACE, "resnet18 fwd: workspace %zu < %zu", ws_bytes, w.bytes);
   const int dt = r.d.dtype, N = r.d.N;
   const int stats_rows = r.d.training ? 1 : 0;
+  ECG_TRY(side_init());
+  static const bool down_side_on = [] { const char* e = getenv("ECGMM_DOWN_SIDE"); return !(e && e[0] == '0'); }();
+  const bool side_fwd = g_side.enabled && down_side_on;
 
   // ---- every conv weight -> compute-dtype operand layouts, one launch.  (Running it on the side stream underneath
   // the stem convolution was measured: no gain -- a cross-stream event wait costs 35-140 us of GPU-side latency on
@@ -307,15 +314,30 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
     // (ConvEpi.wg_rows: the halo kernel writes one partial-sum row per workgroup instead of one per 64 pixels)
     ConvEpi e1 = {}, e2 = {};
     e1.wg_rows = e2.wg_rows = 1;
+    // the downsample branch (1x1 stride-2 conv + its BatchNorm statistics) only meets the main branch at the block's
+    // last pass: it runs on the weight-gradient side stream (idle in the forward) beside conv1 -> bn1 -> conv2
+    hipEvent_t down_done = nullptr;
+    const bool down_side = k.down && side_fwd;
+    if (down_side) {
+      ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
+      side_fork(s);
+      ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, nullptr, nullptr, stats_rows ? w.stats_d : nullptr, 0, g_side.s));
+      ECG_TRY(bn_coef(r, w.stats_d, rows, k.cout, M, params, k.p_dbn, buffers, k.b_dbn, b.coefd, g_side.s));
+      down_done = side_mark();
+    }
     ECG_TRY(ecg_conv_igemm(dt, 0, g1, cur, b.w1f, b.y1, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s, &e1));
     ECG_TRY(bn_coef(r, w.stats, e1.stats_rows, k.cout, M, params, k.p_bn1, buffers, k.b_bn1, b.coef1, s));
     ECG_TRY(ecg_bn_act(dt, b.y1, b.coef1, nullptr, nullptr, nullptr, 1, 1, b.a1, M, k.cout, s));
     ECG_TRY(ecg_conv_igemm(dt, 0, g2, b.a1, b.w2f, b.y2, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s, &e2));
     ECG_TRY(bn_coef(r, w.stats, e2.stats_rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, s));
     if (k.down) {
-      ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
-      ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
-      ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_dbn, buffers, k.b_dbn, b.coefd, s));
+      if (down_side) {
+        main_wait(s, down_done);
+      } else {
+        ConvGeom gd = make_geom(N, k.hin, k.win, k.cin, k.cout, 1, 1, k.stride, 0, 0);
+        ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, nullptr, nullptr, stats_rows ? w.stats : nullptr, 0, s));
+        ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, k.p_dbn, buffers, k.b_dbn, b.coefd, s));
+      }
       ECG_TRY(ecg_bn_act(dt, b.y2, b.coef2, b.yd, b.coefd, nullptr, 1, 1, b.out, M, k.cout, s));
     } else {
       ECG_TRY(ecg_bn_act(dt, b.y2, b.coef2, cur, nullptr, nullptr, 1, 1, b.out, M, k.cout, s));
