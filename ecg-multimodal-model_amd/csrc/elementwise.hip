@@ -781,6 +781,93 @@ __global__ __launch_bounds__(EW_THREADS) void sample_reduce_kernel(const T* __re
   }
 }
 
+// SE-block backward, first pass: ONE read of (dout, out, y) per element yields
+//   dz[n,r,c]  = [out > 0] * dout                        (the residual-branch gradient, stored)
+//   dg[n,c]    = sum_r dz * (y * scale + shift)          (gradient of the SE gate: se_gate_grad)
+//   a1, a2, a3 = sum_r dz, sum_r dz * (y - mean), sum_r (y - mean)
+// from which the BatchNorm-backward reduction of d = dz * gate[n,c] + addc[n,c] follows WITHOUT another pass over the
+// tensors (se_bn_rows_kernel): sum d = sum_n gate a1 + R addc;  sum d (y - mean) = sum_n gate a2 + addc a3.
+// (before: se_gate_grad read the three tensors, then bn_bwd's reduce pass read them again and stored dz)
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void se_gate_bn_kernel(const T* __restrict__ dout, const T* __restrict__ maskref,
+                                                                const T* __restrict__ y, const float* __restrict__ coef,
+                                                                T* __restrict__ dz, float* __restrict__ dg,
+                                                                float* __restrict__ a1o, float* __restrict__ a2o,
+                                                                float* __restrict__ a3o, int R, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float sh[EW_THREADS][VEC + 1];
+  const int cpr = C / VEC, nsl = EW_THREADS / cpr;
+  const int chunk = threadIdx.x % cpr, slice = threadIdx.x / cpr;
+  const int n = blockIdx.x, c0 = chunk * VEC;
+  float sc[VEC], sf[VEC], mu[VEC], ag[VEC], a1[VEC], a2[VEC], a3[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = coef[c0 + j];
+    sf[j] = coef[C + c0 + j];
+    mu[j] = coef[2 * C + c0 + j];
+    ag[j] = a1[j] = a2[j] = a3[j] = 0.f;
+  }
+  for (int r = slice; r < R; r += nsl) {
+    const size_t o = ((size_t)n * R + r) * C + c0;
+    float f[VEC], m[VEC], v[VEC];
+    unpack16<T>(ld16(dout + o), f);
+    unpack16<T>(ld16(maskref + o), m);
+    unpack16<T>(ld16(y + o), v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      f[j] = m[j] > 0.f ? f[j] : 0.f;
+      const float yc = v[j] - mu[j];
+      ag[j] += f[j] * (v[j] * sc[j] + sf[j]);
+      a1[j] += f[j];
+      a2[j] += f[j] * yc;
+      a3[j] += yc;
+    }
+    st16(dz + o, pack16<T>(f));
+  }
+  float* const outs[4] = {dg, a1o, a2o, a3o};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sh[threadIdx.x][j] = q == 0 ? ag[j] : q == 1 ? a1[j] : q == 2 ? a2[j] : a3[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+      const int ck = c / VEC, j = c % VEC;
+      float s_ = 0.f;
+      for (int k = 0; k < nsl; ++k) s_ += sh[k * cpr + ck][j];
+      outs[q][(size_t)n * C + c] = s_;
+    }
+    __syncthreads();
+  }
+}
+
+// SE_ROWS reduction rows [2][C] (sum d, sum d (y - mean)) of d = dz * gate + addc from the per-sample sums above: row j
+// covers the samples n = j (mod SE_ROWS); bn_bwd_finalize_kernel folds the rows.  (One row from one block per 64
+// channels was a 128-deep chain of dependent L2 loads: 45 us.)
+constexpr int SE_ROWS = 16;
+__global__ __launch_bounds__(256) void se_bn_rows_kernel(const float* __restrict__ a1, const float* __restrict__ a2,
+                                                         const float* __restrict__ a3, const float* __restrict__ gate,
+                                                         const float* __restrict__ addc, int N, int R, int C,
+                                                         float* __restrict__ rows) {
+  __shared__ float sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, j = blockIdx.y;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int n = j + SE_ROWS * sl; n < N; n += SE_ROWS * 4) {
+      const size_t o = (size_t)n * C + c;
+      const float g = gate ? gate[o] : 1.f, ad = addc ? addc[o] : 0.f;
+      s1 += g * a1[o] + ad * (float)R;
+      s2 += g * a2[o] + ad * a3[o];
+    }
+  sh[0][sl][threadIdx.x & 63] = s1;
+  sh[1][sl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float* row = rows + (size_t)j * 2 * C;
+    row[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+    row[C + c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+  }
+}
+
 template <typename T>
 __global__ void bcast_rows_kernel(const float* __restrict__ v, T* __restrict__ out, long total, int R, int C,
                                   float scale) {
@@ -1080,7 +1167,8 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
 // maskref as in ecg_bn_bwd (null when `dout` was stored already masked).
 int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, const float* partial, int rows, long M,
-                    int C, float* scratch, hipStream_t stream) {
+                    int C, float* scratch, hipStream_t stream, const float* gate, const float* addc,
+                    int rows_per_sample, float* dbias) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
   if (rows < 1 || rows > 256) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd_tail: %d partial rows (1..256)", rows);
   const int grid = bn_bwd_rows(dtype, M, C);
@@ -1090,10 +1178,16 @@ int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void
   ECG_CHECK_LAUNCH("bn_bwd_finalize");
   BnBwdParams p;
   memset(&p, 0, sizeof(p));
-  p.dout = dout; p.maskref = maskref; p.y = y; p.coef = coef; p.M = M; p.C = C; p.rows_per_sample = 1;
+  p.dout = dout; p.maskref = maskref; p.y = y; p.coef = coef; p.M = M; p.C = C;
+  p.gate = gate; p.addc = addc; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   p.bcoef = bcoef; p.dy = dy;
+  p.partial = dbias ? scratch : nullptr;   // (the finalize above reads `partial`, a different buffer: scratch's rows are free)
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");
+  if (dbias) {
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, (const float*)scratch, grid, C, dbias, 0);
+    ECG_CHECK_LAUNCH("rows_sum");
+  }
   return 0;
 }
 
@@ -1235,6 +1329,30 @@ int ecg_se_gate_grad(int dtype, const void* dout, const void* maskref, const voi
   ECG_CHECK_LAUNCH("se_gate_grad");
   return 0;
 }
+
+// SE-block backward in two tensor passes instead of three (kernels above): se_gate_bn writes dz and the per-sample sums,
+// se_bn_rows turns them (with the gate and the pooled-path gradient addc, known only after the SE MLP's backward) into
+// the BatchNorm-backward reduction row, ecg_bn_bwd_tail finishes (finalize + apply with gate / addc / dbias).
+int ecg_se_gate_bn(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, void* dz,
+                   float* dg, float* a1, float* a2, float* a3, int N, int R, int C, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "se_gate_bn: C=%d unsupported", C);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(se_gate_bn_kernel<bf16_t>, dim3(N), dim3(EW_THREADS), 0, stream, (const bf16_t*)dout,
+                                (const bf16_t*)maskref, (const bf16_t*)y, coef, (bf16_t*)dz, dg, a1, a2, a3, R, C),
+             hipLaunchKernelGGL(se_gate_bn_kernel<float>, dim3(N), dim3(EW_THREADS), 0, stream, (const float*)dout,
+                                (const float*)maskref, (const float*)y, coef, (float*)dz, dg, a1, a2, a3, R, C),
+             "se_gate_bn");
+  ECG_CHECK_LAUNCH("se_gate_bn");
+  return 0;
+}
+int ecg_se_bn_rows(const float* a1, const float* a2, const float* a3, const float* gate, const float* addc, int N, int R,
+                   int C, float* rows, hipStream_t stream) {
+  hipLaunchKernelGGL(se_bn_rows_kernel, dim3(ceil_div(C, 64), SE_ROWS), dim3(256), 0, stream, a1, a2, a3, gate, addc, N, R,
+                     C, rows);
+  ECG_CHECK_LAUNCH("se_bn_rows");
+  return 0;
+}
+int ecg_se_bn_nrows() { return SE_ROWS; }
 
 int ecg_pack_weight(int dtype, const float* w_oihw, void* fwd, void* dgrad, int Cout, int Cin, int RS,
                     hipStream_t stream) {

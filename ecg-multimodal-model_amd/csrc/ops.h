@@ -61,7 +61,13 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
                void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream);
 int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, const float* partial, int rows, long M,
-                    int C, float* scratch, hipStream_t stream);
+                    int C, float* scratch, hipStream_t stream, const float* gate = nullptr, const float* addc = nullptr,
+                    int rows_per_sample = 1, float* dbias = nullptr);
+int ecg_se_gate_bn(int dtype, const void* dout, const void* maskref, const void* y, const float* coef, void* dz,
+                   float* dg, float* a1, float* a2, float* a3, int N, int R, int C, hipStream_t stream);
+int ecg_se_bn_nrows();   // rows ecg_se_bn_rows writes ([rows][2][C])
+int ecg_se_bn_rows(const float* a1, const float* a2, const float* a3, const float* gate, const float* addc, int N, int R,
+                   int C, float* rows, hipStream_t stream);
 int ecg_rows_sum(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t stream);
 int ecg_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, unsigned char* idx, int N, int H, int W,
                        int C, hipStream_t stream);

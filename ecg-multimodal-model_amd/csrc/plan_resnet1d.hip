@@ -122,6 +122,7 @@ void layout_fwd(const R1D& r, void* base, Fwd1& w) {
 struct Bwd1 {
   void* X[2]; void *dz, *dy, *dy1, *dyd, *da, *dtmp, *big0, *big1;
   float *dpooled, *dh1, *dfeat_h, *dg, *ds, *dh, *dm, *dbias_scratch;
+  float *sa1, *sa2, *sa3, *se_rows;   // per-sample sums of the merged SE / BatchNorm backward pass, and its reduction row
   float* bn_scratch;
   void* wg_ws; size_t wg_bytes;
   void* stem_ws; size_t stem_bytes;
@@ -151,6 +152,10 @@ void layout_bwd(const R1D& r, void* base, Bwd1& w) {
   w.dh = a.take<float>((size_t)N * 16);
   w.dm = a.take<float>((size_t)N * 256);
   w.dbias_scratch = a.take<float>(256);
+  w.sa1 = a.take<float>((size_t)N * 256);
+  w.sa2 = a.take<float>((size_t)N * 256);
+  w.sa3 = a.take<float>((size_t)N * 256);
+  w.se_rows = a.take<float>((size_t)ecg_se_bn_nrows() * 2 * 256);
   size_t bn = ecg_bn_bwd_scratch(r.d.dtype, (long)N * r.L1, 64);
   size_t wg = 0;
   size_t lin = ecg_linear_bwd_scratch(N, 256, 64);
@@ -337,8 +342,15 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
       const long M = (long)N * k.lout;
       ConvGeom g1 = make_geom(N, 1, k.lin, k.cin, k.cout, 1, 3, k.stride, 0, 1);
       ConvGeom g2 = make_geom(N, 1, k.lout, k.cout, k.cout, 1, 3, 1, 0, 1);
-      // out = relu(bn2(y2) * g + identity); gate gradient first
-      ECG_TRY(ecg_se_gate_grad(dt, dcur, b.out, b.y2, b.coef2, q.dg, N, k.lout, k.cout, s));
+      // out = relu(bn2(y2) * g + identity); gate gradient first.  Merged form (default): this pass also stores the masked
+      // gradient dz and the per-sample sums the BatchNorm-backward reduction needs, so bn2's backward below is finalize +
+      // apply only -- one read of (dcur, out, y2) less per block.  ECGMM_SE_MERGE=0: the two-pass form.
+      static const bool se_merge = [] { const char* e = getenv("ECGMM_SE_MERGE"); return !(e && e[0] == '0'); }();
+      if (se_merge) {
+        ECG_TRY(ecg_se_gate_bn(dt, dcur, b.out, b.y2, b.coef2, q.dz, q.dg, q.sa1, q.sa2, q.sa3, N, k.lout, k.cout, s));
+      } else {
+        ECG_TRY(ecg_se_gate_grad(dt, dcur, b.out, b.y2, b.coef2, q.dg, N, k.lout, k.cout, s));
+      }
       ECG_TRY(ecg_act_bwd(q.dg, b.g, q.ds, (long)N * k.cout, ECGMM_ACT_SIGMOID, s));
       ECG_TRY(ecg_linear_bwd(q.ds, b.h, P(params, p + 10), q.dh, G(grads, p + 10), G(grads, p + 11), N, k.cr, k.cout,
                              q.lin_ws, q.lin_bytes, s));
@@ -347,8 +359,14 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
                              q.lin_ws, q.lin_bytes, s));
       ECG_TRY(ecg_axpby(1.f / (float)k.lout, q.dm, 0.f, q.dm, (long)N * k.cout, s));
       main_wait(s, g_side1.doneA);  // the previous block's wgrad2 has finished reading q.dy
-      ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, b.g, q.dm, k.lout, b.y2, b.coef2, P(params, p + 6), G(grads, p + 6),
-                         G(grads, p + 7), q.dy, q.dz, G(grads, p + 5), M, k.cout, q.bn_scratch, s));
+      if (se_merge) {
+        ECG_TRY(ecg_se_bn_rows(q.sa1, q.sa2, q.sa3, b.g, q.dm, N, k.lout, k.cout, q.se_rows, s));
+        ECG_TRY(ecg_bn_bwd_tail(dt, q.dz, nullptr, b.y2, b.coef2, P(params, p + 6), G(grads, p + 6), G(grads, p + 7), q.dy,
+                                q.se_rows, ecg_se_bn_nrows(), M, k.cout, q.bn_scratch, s, b.g, q.dm, k.lout, G(grads, p + 5)));
+      } else {
+        ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, b.g, q.dm, k.lout, b.y2, b.coef2, P(params, p + 6), G(grads, p + 6),
+                           G(grads, p + 7), q.dy, q.dz, G(grads, p + 5), M, k.cout, q.bn_scratch, s));
+      }
       if (G(grads, p + 4)) {
         if (side) g_side1.fork(s);
         ECG_TRY(ecg_conv_wgrad(dt, g2, b.a1, q.dy, G(grads, p + 4), 0, q.wg_ws, q.wg_bytes, wst));
