@@ -101,7 +101,11 @@ template <int BN> struct HaloCfg {
   static constexpr int NPW_MAX = HCAP / 64;           // halo DMA pieces per wave per channel slice
 };
 
-template <int BN, int RS, int MODE>
+// NCS1: instantiation for ONE channel slice per tile (Cs = 64).  The second halo buffer is then idle during a tile's K
+// loop, so the NEXT tile's halo is fetched there during this tile's K loop (through the same in-loop piece schedule
+// that otherwise fetches the next channel slice) instead of from the epilogue, where only ~0.6 us of work covered its
+// HBM latency: 1.5-2 us of exposed wait per tile, 12 tiles per workgroup on the 56x56 layers.
+template <int BN, int RS, int MODE, bool NCS1 = false>
 __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   using C = HaloCfg<BN>;
   constexpr int TP = 4;         // 16-pixel tiles per wave (64 pixels)
@@ -249,9 +253,11 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   set_wrow(wrow, n0);
   int g0 = 0;  // K steps done so far (all tiles): step g uses weight slot g & 3
   int qs = 0;  // channel slices done so far: slice q uses halo buffer q & 1
-  auto tile_fills = [&](int m0_) {
-    set_hoff(m0_);
-    dma_halo((unsigned)(qs & 1) * C::HBUF, 0, 0, C::NPW_MAX);
+  auto tile_fills = [&](int m0_, bool with_halo) {
+    if (with_halo) {
+      set_hoff(m0_);
+      dma_halo((unsigned)(qs & 1) * C::HBUF, 0, 0, C::NPW_MAX);
+    }
     dma_w(wrow, g0 & 3, 0, 0);
     dma_w(wrow, (g0 + 1) & 3, 0, 1);
     dma_w(wrow, (g0 + 2) & 3, 0, 2);
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   float* const scoef = reinterpret_cast<float*>(smem + C::CBASE);
   if (MODE == 1 && p.red_y)
     for (int i = tid; i < 3 * BN; i += HTHREADS) scoef[i] = p.red_coef[(i / BN) * p.Cd + n0 + (i % BN)];
-  tile_fills(m0);
+  tile_fills(m0, true);
 
   u32x4 fa0[TC], fb0[TP], fa1[TC], fb1[TP];
 
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       for (int b = 0; b < TP; ++b) fb1[b] = ld_b((bad(b, t) ^ 64u) + hb);
       // (b) fills THREE steps ahead: weights of step s + 3 go into the slot step s - 1 read (every wave is past that step's
       // barrier), the next slice's halo into the other halo buffer.  Two steps' fills stay in flight across each barrier.
-      const auto n_halo = [](int tt, bool last) { return (!last && tt < RS - 1 && tt * HPS < C::NPW_MAX)
+      const auto n_halo = [](int tt, bool last) { return (!(last && !NCS1) && tt < RS - 1 && tt * HPS < C::NPW_MAX)
                                                       ? ((tt + 1) * HPS < C::NPW_MAX ? HPS : C::NPW_MAX - tt * HPS) : 0; };
       const auto n_fill = [&](int tt, bool last) {
         return ((last && tt + 3 >= RS) ? 0 : C::WPS) + n_halo(tt, last) + ((last && tt == 0) ? 3 : 0);
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       if (LAST && t == 0) prefetch_epilogue_operands();   // 3 DMAs, counted in n_fill
 #if !(defined(HALO_ABL) && HALO_ABL == 3)   // diagnostic 3: no fills inside the K loop
       if (!(LAST && wrap)) dma_w(wrow, (s + 3) & 3, cs + (wrap ? 1 : 0), (t + 3) % RS);
-      if (n_halo(t, LAST) > 0) dma_halo(hbn, cs + 1, t * HPS, (t + 1) * HPS);
+      if (n_halo(t, LAST) > 0) dma_halo(hbn, NCS1 ? 0 : cs + 1, t * HPS, (t + 1) * HPS);   // (NCS1: the next TILE's halo, hoff set at the tile's start)
 #endif
       // (c) k-step 0
       mma(fa0, fb0);
@@ -366,6 +372,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   for (;;) {
     set_baddr(m0);
     zero_acc();
+    if (NCS1) set_hoff(mt + Gk < p.ntm ? (mt + Gk) * HBM_ : p.M + 4 * HBM_);   // next tile's halo offsets (none left: all out of range)
     // This tile's first fills have landed.  They were issued BEFORE the previous tile's output stores, and vmcnt retires
     // in issue order: waiting for "all but the N youngest", N = the store instructions of that epilogue, leaves the
     // stores in flight (a vmcnt(0) here exposed their whole write latency once per tile).  N must not exceed what was
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       using H1 = std::integral_constant<int, 1>;
       if (addend == nullptr && !red) {
         // nothing to load: fills first (they have the whole epilogue to land), stores as soon as a half is computed
-        if (more) tile_fills(m0);
+        if (more) tile_fills(m0, !NCS1);
         __builtin_amdgcn_sched_barrier(0);
         compute(H0{});
         stores(H0{});
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
         compute(H0{});
         loads(H1{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more) tile_fills(m0);
+        if (more) tile_fills(m0, !NCS1);
         __builtin_amdgcn_sched_barrier(0);
         stores(H0{});
         compute(H1{});
@@ -646,14 +653,14 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   }
 }
 
-template <int BN, int RS, int MODE>
+template <int BN, int RS, int MODE, bool NCS1 = false>
 int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   using C = HaloCfg<BN>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS) != hipSuccess)
       ECG_FAIL(ECGMM_ERR_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", C::LDS);
     attr_set[dev] = true;
@@ -674,7 +681,7 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   if (Gk > q.ntm) Gk = q.ntm;
   if (Gk < 1) Gk = 1;
   *rows_out = Gk;
-  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE>), dim3(Gk * q.ntn), dim3(HTHREADS), C::LDS, stream, q);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1>), dim3(Gk * q.ntn), dim3(HTHREADS), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
   return 0;
 }
@@ -756,7 +763,12 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
   // MODE 2 = input gradient WITHOUT the fused BatchNorm-backward reduction compiled in: the reduction's operand registers
   // push the BN = 128 instantiation over its 256-VGPR budget (396 B of scratch per lane) whether or not a launch uses it --
   // 13 us of a 88 us layer-2 launch (tools/halo_abl.sh, ablation 7)
-  if (g.R == 3) {
+  static const bool ncs1_on = [] { const char* e = getenv("ECGMM_HALO_NCS1"); return !(e && e[0] == '0'); }();
+  if (g.R == 3 && !wide && p.ncs == 1 && ncs1_on) {   // the 64 -> 64 channel 3x3 layers: next tile's halo during the K loop
+    if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
+    else if (p.red_y) rc = launch_halo<64, 9, 1, true>(p, &wg, stream);
+    else rc = launch_halo<64, 9, 2, true>(p, &wg, stream);
+  } else if (g.R == 3) {
     if (mode == 0) rc = wide ? launch_halo<128, 9, 0>(p, &wg, stream) : launch_halo<64, 9, 0>(p, &wg, stream);
     else if (p.red_y) rc = wide ? launch_halo<128, 9, 1>(p, &wg, stream) : launch_halo<64, 9, 1>(p, &wg, stream);
     else rc = wide ? launch_halo<128, 9, 2>(p, &wg, stream) : launch_halo<64, 9, 2>(p, &wg, stream);
