@@ -496,9 +496,136 @@ __global__ __launch_bounds__(256) void dense16_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Squeeze-excite MLP (SEBlock.fc, multimodal_paper_modal_balance.py:35-46): g = sigmoid(W2 relu(W1 m + b1) + b2) per
+// sample, C -> C/16 -> C.  As per-op launches it is 2 kernels forward and 7 backward (two act_bwd, two Linear backward
+// = dgrad + wgrad each, a scale) of 5-9 us each, in the middle of every residual block's dependency chain; here one
+// kernel forward, two backward (per-sample part; weight / bias gradients summed over the batch in a fixed order).
+// ------------------------------------------------------------------------------------------------
+constexpr int SE_MAXC = 1024, SE_MAXR = 64;
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ m, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ h,
+                                                         float* __restrict__ g, int C, int CR) {
+  __shared__ float sm[SE_MAXC], shh[SE_MAXR];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < C; c += 256) sm[c] = m[(size_t)n * C + c];
+  __syncthreads();
+  for (int j = wv; j < CR; j += 4) {   // one wave per hidden unit: strided partial sums, butterfly, + bias (linear_fwd_kernel)
+    float t = 0.f;
+    for (int c = lane; c < C; c += 64) t += sm[c] * w1[(size_t)j * C + c];
+    t = wave_sum(t);
+    if (lane == 0) {
+      const float v = fmaxf(t + b1[j], 0.f);
+      shh[j] = v;
+      h[(size_t)n * CR + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int j = 0; j < CR; ++j) t += shh[j] * w2[(size_t)c * CR + j];
+    g[(size_t)n * C + c] = 1.f / (1.f + expf(-(t + b2[c])));
+  }
+}
+
+// per sample: ds = dg * g (1 - g);  dh = (ds W2) * [h > 0];  dm = (dh W1) * scale      (scale = 1 / L: the mean over L)
+__global__ __launch_bounds__(256) void se_mlp_bwd_samples_kernel(const float* __restrict__ dg, const float* __restrict__ g,
+                                                                 const float* __restrict__ h, const float* __restrict__ w1,
+                                                                 const float* __restrict__ w2, float* __restrict__ ds,
+                                                                 float* __restrict__ dh, float* __restrict__ dm, int C,
+                                                                 int CR, float scale) {
+  __shared__ float sds[SE_MAXC], sdh[SE_MAXR];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float gv = g[(size_t)n * C + c];
+    const float v = dg[(size_t)n * C + c] * gv * (1.f - gv);
+    sds[c] = v;
+    ds[(size_t)n * C + c] = v;
+  }
+  __syncthreads();
+  for (int j = wv; j < CR; j += 4) {
+    float t = 0.f;
+    for (int c = lane; c < C; c += 64) t += sds[c] * w2[(size_t)c * CR + j];
+    t = wave_sum(t);
+    if (lane == 0) {
+      const float v = h[(size_t)n * CR + j] > 0.f ? t : 0.f;
+      sdh[j] = v;
+      dh[(size_t)n * CR + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int j = 0; j < CR; ++j) t += sdh[j] * w1[(size_t)j * C + c];
+    dm[(size_t)n * C + c] = t * scale;
+  }
+}
+
+// dW2[c][j] = sum_n ds[n][c] h[n][j], db2[c] = sum_n ds[n][c], dW1[j][c] = sum_n dh[n][j] m[n][c], db1[j] = sum_n dh[n][j]
+// One output per 4 threads (sample slices n = s mod 4), folded in LDS in a fixed order.  Null outputs are skipped.
+__global__ __launch_bounds__(256) void se_mlp_bwd_weights_kernel(const float* __restrict__ ds, const float* __restrict__ dh,
+                                                                 const float* __restrict__ h, const float* __restrict__ m,
+                                                                 float* __restrict__ dw1, float* __restrict__ db1,
+                                                                 float* __restrict__ dw2, float* __restrict__ db2, int N,
+                                                                 int C, int CR) {
+  __shared__ float sh[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const int T2 = C * CR, T = 2 * T2 + C + CR;
+  float acc = 0.f;
+  float* dst = nullptr;
+  if (o < T) {
+    if (o < T2) {                       // dW2[c][j]
+      const int c = o / CR, j = o - c * CR;
+      dst = dw2 ? dw2 + o : nullptr;
+      if (dst) for (int n = sl; n < N; n += 4) acc += ds[(size_t)n * C + c] * h[(size_t)n * CR + j];
+    } else if (o < 2 * T2) {            // dW1[j][c]
+      const int q = o - T2, j = q / C, c = q - j * C;
+      dst = dw1 ? dw1 + q : nullptr;
+      if (dst) for (int n = sl; n < N; n += 4) acc += dh[(size_t)n * CR + j] * m[(size_t)n * C + c];
+    } else if (o < 2 * T2 + C) {        // db2[c]
+      const int c = o - 2 * T2;
+      dst = db2 ? db2 + c : nullptr;
+      if (dst) for (int n = sl; n < N; n += 4) acc += ds[(size_t)n * C + c];
+    } else {                            // db1[j]
+      const int j = o - 2 * T2 - C;
+      dst = db1 ? db1 + j : nullptr;
+      if (dst) for (int n = sl; n < N; n += 4) acc += dh[(size_t)n * CR + j];
+    }
+  }
+  sh[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && dst) *dst = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+bool ecg_se_mlp_fused_ok(int C, int CR) {
+  static const bool on = [] { const char* e = getenv("ECGMM_SE_MLP_FUSED"); return !(e && e[0] == '0'); }();
+  return on && C >= 1 && C <= SE_MAXC && CR >= 1 && CR <= SE_MAXR;
+}
+int ecg_se_mlp_fwd(const float* m, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* g,
+                   int N, int C, int CR, hipStream_t s) {
+  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), 0, s, m, w1, b1, w2, b2, h, g, C, CR);
+  ECG_CHECK_LAUNCH("se_mlp_fwd");
+  return 0;
+}
+// ds [N][C] and dh [N][CR] are scratch outputs of the per-sample kernel, consumed by the weight kernel
+int ecg_se_mlp_bwd(const float* dg, const float* g, const float* h, const float* m, const float* w1, const float* w2,
+                   float* ds, float* dh, float* dm, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int CR,
+                   float scale, hipStream_t s) {
+  hipLaunchKernelGGL(se_mlp_bwd_samples_kernel, dim3(N), dim3(256), 0, s, dg, g, h, w1, w2, ds, dh, dm, C, CR, scale);
+  ECG_CHECK_LAUNCH("se_mlp_bwd_samples");
+  if (dw1 || db1 || dw2 || db2) {
+    const int T = 2 * C * CR + C + CR;
+    hipLaunchKernelGGL(se_mlp_bwd_weights_kernel, dim3((T + 63) / 64), dim3(256), 0, s, (const float*)ds, (const float*)dh, h,
+                       m, dw1, db1, dw2, db2, N, C, CR);
+    ECG_CHECK_LAUNCH("se_mlp_bwd_weights");
+  }
+  return 0;
+}
 
 // Can the fused head serve this description?  (dims <= 512, classes <= 4, MFMA-tileable sizes)
 bool ecg_head_fused_ok(const int* dim, int B, int hidden, int num_classes) {

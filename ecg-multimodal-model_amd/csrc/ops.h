@@ -129,6 +129,12 @@ int ecg_head_rows_bwd(const float* const* raw, const float* const* ln_g, const f
 int ecg_head_finalize(const float* partial, int rows, const int* dim, int NC, float* const* g_ln, float* const* g_cls,
                       float* g_aw, float* g_fg, float* g_fb, const float* aw, const int* have, const int* have_cls,
                       int have_fusion, const float* dz, int B, int H, float* fc0_db, hipStream_t s);
+bool ecg_se_mlp_fused_ok(int C, int CR);
+int ecg_se_mlp_fwd(const float* m, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* g,
+                   int N, int C, int CR, hipStream_t s);
+int ecg_se_mlp_bwd(const float* dg, const float* g, const float* h, const float* m, const float* w1, const float* w2,
+                   float* ds, float* dh, float* dm, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int CR,
+                   float scale, hipStream_t s);
 bool ecg_dense16_ok(const void* a, const void* b, const void* c, int B, int In, int Out);
 int ecg_dense16_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, int act,
                     hipStream_t s);

@@ -271,9 +271,14 @@ extern "C" int ecgmm_resnet1d_forward(const ecgmm_resnet1d_desc* d, const float*
     ECG_TRY(bn_coef(r, w.stats, rows, k.cout, M, params, p + 6, buffers, bb + 3, b.coef2, s));
     // squeeze-excite gate from mean_L(bn2(y2))
     ECG_TRY(ecg_avgpool(dt, b.y2, b.m, N, k.lout, k.cout, b.coef2, s));
-    ECG_TRY(ecg_linear_fwd(b.m, P(params, p + 8), P(params, p + 9), b.h, N, k.cout, k.cr, ECGMM_ACT_RELU, nullptr, s));
-    ECG_TRY(ecg_linear_fwd(b.h, P(params, p + 10), P(params, p + 11), b.g, N, k.cr, k.cout, ECGMM_ACT_SIGMOID, nullptr,
-                           s));
+    if (ecg_se_mlp_fused_ok(k.cout, k.cr)) {
+      ECG_TRY(ecg_se_mlp_fwd(b.m, P(params, p + 8), P(params, p + 9), P(params, p + 10), P(params, p + 11), b.h, b.g, N,
+                             k.cout, k.cr, s));
+    } else {
+      ECG_TRY(ecg_linear_fwd(b.m, P(params, p + 8), P(params, p + 9), b.h, N, k.cout, k.cr, ECGMM_ACT_RELU, nullptr, s));
+      ECG_TRY(ecg_linear_fwd(b.h, P(params, p + 10), P(params, p + 11), b.g, N, k.cr, k.cout, ECGMM_ACT_SIGMOID, nullptr,
+                             s));
+    }
     if (k.down) {
       ConvGeom gd = make_geom(N, 1, k.lin, k.cin, k.cout, 1, 1, k.stride, 0, 0);
       ECG_TRY(ecg_conv_igemm(dt, 0, gd, cur, b.wdf, b.yd, P(params, p + 13), nullptr, st, 0, s));
@@ -351,13 +356,18 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
       } else {
         ECG_TRY(ecg_se_gate_grad(dt, dcur, b.out, b.y2, b.coef2, q.dg, N, k.lout, k.cout, s));
       }
-      ECG_TRY(ecg_act_bwd(q.dg, b.g, q.ds, (long)N * k.cout, ECGMM_ACT_SIGMOID, s));
-      ECG_TRY(ecg_linear_bwd(q.ds, b.h, P(params, p + 10), q.dh, G(grads, p + 10), G(grads, p + 11), N, k.cr, k.cout,
-                             q.lin_ws, q.lin_bytes, s));
-      ECG_TRY(ecg_act_bwd(q.dh, b.h, q.dh, (long)N * k.cr, ECGMM_ACT_RELU, s));
-      ECG_TRY(ecg_linear_bwd(q.dh, b.m, P(params, p + 8), q.dm, G(grads, p + 8), G(grads, p + 9), N, k.cout, k.cr,
-                             q.lin_ws, q.lin_bytes, s));
-      ECG_TRY(ecg_axpby(1.f / (float)k.lout, q.dm, 0.f, q.dm, (long)N * k.cout, s));
+      if (ecg_se_mlp_fused_ok(k.cout, k.cr)) {   // the SE MLP's backward in two launches (head_fused.hip)
+        ECG_TRY(ecg_se_mlp_bwd(q.dg, b.g, b.h, b.m, P(params, p + 8), P(params, p + 10), q.ds, q.dh, q.dm, G(grads, p + 8),
+                               G(grads, p + 9), G(grads, p + 10), G(grads, p + 11), N, k.cout, k.cr, 1.f / (float)k.lout, s));
+      } else {
+        ECG_TRY(ecg_act_bwd(q.dg, b.g, q.ds, (long)N * k.cout, ECGMM_ACT_SIGMOID, s));
+        ECG_TRY(ecg_linear_bwd(q.ds, b.h, P(params, p + 10), q.dh, G(grads, p + 10), G(grads, p + 11), N, k.cr, k.cout,
+                               q.lin_ws, q.lin_bytes, s));
+        ECG_TRY(ecg_act_bwd(q.dh, b.h, q.dh, (long)N * k.cr, ECGMM_ACT_RELU, s));
+        ECG_TRY(ecg_linear_bwd(q.dh, b.m, P(params, p + 8), q.dm, G(grads, p + 8), G(grads, p + 9), N, k.cout, k.cr,
+                               q.lin_ws, q.lin_bytes, s));
+        ECG_TRY(ecg_axpby(1.f / (float)k.lout, q.dm, 0.f, q.dm, (long)N * k.cout, s));
+      }
       main_wait(s, g_side1.doneA);  // the previous block's wgrad2 has finished reading q.dy
       if (se_merge) {
         ECG_TRY(ecg_se_bn_rows(q.sa1, q.sa2, q.sa3, b.g, q.dm, N, k.lout, k.cout, q.se_rows, s));
