@@ -247,7 +247,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    ddp = DataParallel(model, force=force_ddp) if (world > 1 or force_ddp) else None
+    # ECGMM_DDP_OVERLAP=0 (A/B): one all-reduce pass after the backward instead of per-stage-group launches on a comm stream
+    ddp = (DataParallel(model, force=force_ddp, overlap=os.environ.get("ECGMM_DDP_OVERLAP", "1") != "0")
+           if (world > 1 or force_ddp) else None)
     opt = FusedAdam((p for p in model.parameters() if p.requires_grad), lr=1e-4, grad_scale=1.0 / world)
 
     def step():

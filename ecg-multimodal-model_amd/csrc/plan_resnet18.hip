@@ -250,6 +250,20 @@ extern "C" int ecgmm_side_wait(void* stream) {
   return g_side.wait_on((hipStream_t)stream);
 }
 
+// The library's weight-gradient side stream (NULL when it is switched off), and "fork": everything enqueued on `stream`
+// so far happens-before later work on the side stream.  A data-parallel host issues its early all-reduces from the side
+// stream's context (after a fork) instead of from a stream of its own: a fifth busy HIP stream oversubscribes the four
+// hardware queues (GPU_MAX_HW_QUEUES), and two streams that share a queue serialise each other's event waits.
+extern "C" void* ecgmm_side_stream(void) {
+  if (side_init() != 0 || !g_side.enabled) return nullptr;
+  return (void*)g_side.s;
+}
+extern "C" int ecgmm_side_fork(void* stream) {
+  ECG_TRY(side_init());
+  if (g_side.enabled) g_side.fork((hipStream_t)stream);
+  return 0;
+}
+
 extern "C" size_t ecgmm_resnet18_fwd_workspace(const ecgmm_resnet18_desc* d) {
   R18 r;
   if (build(d, r)) return 0;

@@ -209,6 +209,18 @@ int ecg_resnet1d_side_enable(int on) {
   g_side1.enabled = on != 0;
   return 0;
 }
+// The ResNet1D_SE plan's own switch.  Beside the image encoder (multimodal model: the signal encoder already runs on a
+// side stream of the host's) its weight gradients stay on the encoder's stream: HIP maps streams onto four hardware
+// queues, and a fifth busy stream -- with data parallelism the process group's stream is one more -- shares a queue with
+// another, whose event waits then serialise both (same-call A/B: 7.15 -> 7.09 ms/step, and the one-rank rehearsal of the
+// data-parallel path 7.52 -> 7.17).  Alone (12-lead configuration) the side stream is worth 3 %.
+// (a hint ANDed with the global switch ecgmm_side_wgrad / ECGMM_SIDE_WGRAD, so profiling runs that turn every side
+// stream off stay serialized)
+static bool g_side1_alone = true;
+extern "C" int ecgmm_resnet1d_side_wgrad(int on) {
+  g_side1_alone = on != 0;
+  return 0;
+}
 
 extern "C" size_t ecgmm_resnet1d_fwd_workspace(const ecgmm_resnet1d_desc* d) {
   R1D r;
@@ -317,7 +329,7 @@ extern "C" int ecgmm_resnet1d_backward(const ecgmm_resnet1d_desc* d, const float
     ECG_FAIL(ECGMM_ERR_WORKSPACE, "resnet1d bwd: workspace %zu < %zu", ws_bwd_bytes, q.bytes);
   const int dt = r.d.dtype, N = r.d.N, cin = r.d.cin;
   ECG_TRY(g_side1.init());
-  const bool side = g_side1.enabled;
+  const bool side = g_side1.enabled && g_side1_alone;
   // weight gradients of this call run beside the dgrad chain: narrow launches (conv_wgrad.hip, pick_nsplit)
   ecg_conv_wgrad_narrow(side);
   struct NarrowOff { ~NarrowOff() { ecg_conv_wgrad_narrow(false); } } narrow_off;

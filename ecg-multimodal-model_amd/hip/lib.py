@@ -56,7 +56,10 @@ SIGNATURES = {
     "ecgmm_conv_wgrad_ring_enable": (i32, [i32]),
     "ecgmm_side_wgrad": (i32, [i32]),
     "ecgmm_side_defer_join": (i32, [i32]),
+    "ecgmm_resnet1d_side_wgrad": (i32, [i32]),
     "ecgmm_side_wait": (i32, [vp]),
+    "ecgmm_side_stream": (vp, []),
+    "ecgmm_side_fork": (i32, [vp]),
     "ecgmm_resnet1d_fwd_workspace": (sz, [P(ResNet1DDesc)]),
     "ecgmm_resnet1d_bwd_workspace": (sz, [P(ResNet1DDesc)]),
     "ecgmm_resnet1d_forward": (i32, [P(ResNet1DDesc), vp, P(vp), P(vp), vp, vp, sz, vp]),

@@ -105,6 +105,12 @@ class ResNet1D_SE(nn.Module):
         spec.dropout_p = float(self.classifier[3].p) if self.classifier[3].training else 0.0
         spec.buffers = list(self.buffers())
         params = list(self.parameters())
+        if x.is_cuda:
+            # weight gradients on the plan's own side stream only when this encoder has the GPU to itself: beside the
+            # image encoder (ECGMultimodalModel sets _beside_image_encoder) a fifth busy stream oversubscribes the
+            # four hardware queues (csrc/plan_resnet1d.hip, ecgmm_resnet1d_side_wgrad)
+            from .hip import lib as _L
+            _L.lib().ecgmm_resnet1d_side_wgrad(0 if getattr(self, "_beside_image_encoder", False) else 1)
         if len(params) != 52 or len(spec.buffers) != 27:
             raise RuntimeError(f"ResNet1D_SE expects 52 parameters / 27 buffers, found {len(params)} / {len(spec.buffers)}")
         return E.run_plan(x, spec, params)
@@ -207,6 +213,7 @@ class ECGMultimodalModel(nn.Module):
             main = torch.cuda.current_stream(image.device)
             side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(image.device)
             side.wait_stream(main)
+            self.signal_encoder._beside_image_encoder = True
             with torch.cuda.stream(side):
                 signal_raw = self.signal_encoder(ecg_signal)
                 clinical_raw = self._clinical_forward(clinical)
@@ -215,6 +222,7 @@ class ECGMultimodalModel(nn.Module):
             signal_raw.record_stream(main)
             clinical_raw.record_stream(main)
         else:
+            self.signal_encoder._beside_image_encoder = False
             image_raw = self.image_encoder(image)
             signal_raw = self.signal_encoder(ecg_signal)
             clinical_raw = self._clinical_forward(clinical)

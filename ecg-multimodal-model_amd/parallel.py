@@ -8,8 +8,11 @@ backward stages still run (``DataParallel`` installs backward-stage hooks on the
 the 1/world scale is folded into the fused Adam (``grad_scale``) instead of a separate pass.
 BatchNorm statistics stay per replica, as torch DDP does.
 """
+import os
 import torch
 import torch.distributed as dist
+
+_SKIP_AR = os.environ.get("ECGMM_DDP_SKIP_AR") == "1"   # diagnostic: staged launches without the collective itself
 
 
 def flatten(model, only_trainable=True):
@@ -56,6 +59,10 @@ class DataParallel(torch.nn.Module):
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self._pending = []
         self._comm_stream = None
+        import os
+        self._tail_on_compute = os.environ.get("ECGMM_DDP_TAIL_ON_COMPUTE", "1") != "0"
+        self._ar_from_side = os.environ.get("ECGMM_DDP_AR_FROM_SIDE", "1") != "0"
+        self._works = []
         self.force = force and dist.is_initialized()
         self.overlap = overlap and (self.world > 1 or self.force) and self.flat_g.is_cuda
         if self.world > 1 or self.force:
@@ -84,8 +91,13 @@ class DataParallel(torch.nn.Module):
         enc = getattr(self.module, "image_encoder", None)
         if enc is None or not hasattr(enc, "_spec"):
             return
-        groups = [(0, 3), (3, 5), (5, 10)]           # fc+layer4 | layer3 | layer2, layer1, stem
-        owners = [[enc.fc, enc.layer4], [enc.layer3], [enc.layer2, enc.layer1, enc.conv1, enc.bn1]]
+        import os
+        if os.environ.get("ECGMM_DDP_GROUPS", "3") == "2":
+            groups = [(0, 3), (3, 10)]               # fc+layer4 (70 % of the bytes) | everything else
+            owners = [[enc.fc, enc.layer4], [enc.layer3, enc.layer2, enc.layer1, enc.conv1, enc.bn1]]
+        else:
+            groups = [(0, 3), (3, 5), (5, 10)]       # fc+layer4 | layer3 | layer2, layer1, stem
+            owners = [[enc.fc, enc.layer4], [enc.layer3], [enc.layer2, enc.layer1, enc.conv1, enc.bn1]]
         ranges = []
         for mods in owners:
             ps = [p for m in mods for p in m.parameters() if p.requires_grad]
@@ -96,11 +108,42 @@ class DataParallel(torch.nn.Module):
 
     def _stage_hook(self, spec, gi):
         r = self._enc_ranges[gi]
-        if r is not None:
-            self._launch(r[0], r[1], side=True)
-            self._done_ranges.append(r)
+        if r is None or os.environ.get("ECGMM_DDP_HOOK_NOOP") == "1":   # (diagnostic: split backward, no launches)
+            return
+        if gi == len(self._enc_ranges) - 1 and self._tail_on_compute:
+            # Nothing is left to overlap the LAST group's all-reduce with, and every stream hop costs ~80-100 us of exposed
+            # latency on this platform (compute -> comm stream -> the process group's own stream -> comm -> compute = 4
+            # hops, 0.32 ms in the one-rank rehearsal): the last group is reduced by reduce_gradients() on the compute
+            # stream itself (2 hops), together with the parameters outside the image encoder.
+            return
+        self._launch(r[0], r[1], side=True)
+        self._done_ranges.append(r)
+
+    def _launch_from_side_stream(self, lo, hi):
+        """Early (overlapped) all-reduce issued from the library's weight-gradient side stream: that stream is forked from
+        the compute stream (so it also covers the gradients the compute stream wrote), the collective itself runs on the
+        process group's own stream, and the handles are waited for in reduce_gradients().  No extra HIP stream."""
+        from .hip import lib as L
+        lib = L.lib()
+        ptr = lib.ecgmm_side_stream()
+        if not ptr:
+            return False
+        cur = torch.cuda.current_stream()
+        L.check(lib.ecgmm_side_fork(cur.cuda_stream), "side_fork")
+        ext = self._side_ext = getattr(self, "_side_ext", None) or torch.cuda.ExternalStream(ptr, device=cur.device)
+        with torch.cuda.stream(ext):
+            pos = lo
+            while pos < hi:
+                end = min(hi, pos + self.bucket_elems)
+                if not _SKIP_AR:
+                    self._works.append(dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg,
+                                                       async_op=True))
+                pos = end
+        return True
 
     def _launch(self, lo, hi, side=False):
+        if side and self._ar_from_side and self._launch_from_side_stream(lo, hi):
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm_stream):
@@ -113,11 +156,13 @@ class DataParallel(torch.nn.Module):
             pos = lo
             while pos < hi:
                 end = min(hi, pos + self.bucket_elems)
-                dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg)
+                if not _SKIP_AR:
+                    dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg)
                 pos = end
 
     def prepare_backward(self):
         self._done_ranges = []
+        self._works = []
 
     def reduce_gradients(self):
         """All-reduce whatever the stage hooks have not already shipped, then make the compute
@@ -134,8 +179,21 @@ class DataParallel(torch.nn.Module):
         if pos < total:
             todo.append((pos, total))
         if self.overlap:
-            for lo, hi in todo:
-                self._launch(lo, hi)
+            if self._tail_on_compute:
+                # (the backward has returned: autograd has already joined every stream it used to the compute stream,
+                # and the last stage group's plan call joined the weight-gradient side stream)
+                for lo, hi in todo:
+                    p = lo
+                    while p < hi:
+                        e = min(hi, p + self.bucket_elems)
+                        dist.all_reduce(self.flat_g[p:e], op=dist.ReduceOp.SUM, group=self.pg)
+                        p = e
+            else:
+                for lo, hi in todo:
+                    self._launch(lo, hi)
+            for w in getattr(self, "_works", []):
+                w.wait()           # (orders the compute stream after the collective; no host block)
+            self._works = []
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         else:
             for lo, hi in todo:

@@ -73,7 +73,15 @@ int ecgmm_side_wgrad(int on);
  * stream; ecgmm_side_wait(stream) orders `stream` (the all-reduce stream) after the weight gradients issued so
  * far.  The last stage group of a backward must run with defer = 0. */
 int ecgmm_side_defer_join(int defer);
+/* the same switch for the ResNet1D_SE plan alone (ecgmm_side_wgrad sets both): a host that already runs the signal encoder
+ * on a side stream of its own beside the image encoder turns it off -- more than four busy HIP streams share hardware queues */
+int ecgmm_resnet1d_side_wgrad(int on);
 int ecgmm_side_wait(void* stream);
+/* The side stream itself (a hipStream_t, NULL when switched off) and "fork" (work enqueued on `stream` so far happens-before
+ * later work on the side stream): a data-parallel host can issue its overlapped all-reduces from the side stream's
+ * context instead of a stream of its own -- a fifth busy stream oversubscribes the four hardware queues. */
+void* ecgmm_side_stream(void);
+int ecgmm_side_fork(void* stream);
 
 #define ECGMM_RESNET1D_NPARAMS 52
 #define ECGMM_RESNET1D_NBUFFERS 27

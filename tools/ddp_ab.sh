@@ -1,11 +1,9 @@
-# one-rank rehearsal of the data-parallel step (hooks, comm stream, bucketed all-reduce): deferred side-stream join on/off
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/ddp; mkdir -p $O
-python3 -m pytest tests/test_parallel_gpu.py -x -q > $O/test.log 2>&1 || { tail -30 $O/test.log; exit 1; }
-tail -2 $O/test.log
+run() { env "$@" python3 bench.py --no-cpu-baseline --no-prof $A 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['step_ms_hipevent']['median'])"; }
 for i in 1 2; do
-python3 bench.py --no-cpu-baseline --no-prof --steps 40 --warmup 10 > $O/plain_$i.json 2>/dev/null || exit 1
-ECGMM_FORCE_DDP=1 ECGMM_DDP_DEFER_JOIN=0 python3 bench.py --no-cpu-baseline --no-prof --steps 40 --warmup 10 > $O/ddp_join_$i.json 2>/dev/null || exit 1
-ECGMM_FORCE_DDP=1 python3 bench.py --no-cpu-baseline --no-prof --steps 40 --warmup 10 > $O/ddp_defer_$i.json 2>/dev/null || exit 1
+A=""
+echo "== plain"; run ECGMM_NOP=1
+echo "== force ddp"; run ECGMM_FORCE_DDP=1
+A="--workload signal12 --batch 512"
+echo "== signal12"; run ECGMM_NOP=1
 done
-for f in $O/*.json; do python3 -c "import json,sys; d=json.load(open('$f')); print('$f', d['ms_per_step'])"; done
