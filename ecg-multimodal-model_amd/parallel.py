@@ -12,7 +12,6 @@ import os
 import torch
 import torch.distributed as dist
 
-_SKIP_AR = os.environ.get("ECGMM_DDP_SKIP_AR") == "1"   # diagnostic: staged launches without the collective itself
 
 
 def flatten(model, only_trainable=True):
@@ -108,7 +107,7 @@ class DataParallel(torch.nn.Module):
 
     def _stage_hook(self, spec, gi):
         r = self._enc_ranges[gi]
-        if r is None or os.environ.get("ECGMM_DDP_HOOK_NOOP") == "1":   # (diagnostic: split backward, no launches)
+        if r is None:
             return
         if gi == len(self._enc_ranges) - 1 and self._tail_on_compute:
             # Nothing is left to overlap the LAST group's all-reduce with, and every stream hop costs ~80-100 us of exposed
@@ -135,9 +134,8 @@ class DataParallel(torch.nn.Module):
             pos = lo
             while pos < hi:
                 end = min(hi, pos + self.bucket_elems)
-                if not _SKIP_AR:
-                    self._works.append(dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg,
-                                                       async_op=True))
+                self._works.append(dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg,
+                                                   async_op=True))
                 pos = end
         return True
 
@@ -156,8 +154,7 @@ class DataParallel(torch.nn.Module):
             pos = lo
             while pos < hi:
                 end = min(hi, pos + self.bucket_elems)
-                if not _SKIP_AR:
-                    dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg)
+                dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg)
                 pos = end
 
     def prepare_backward(self):
