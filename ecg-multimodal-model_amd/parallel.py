@@ -144,6 +144,7 @@ class DataParallel(torch.nn.Module):
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        self._comm_used = True
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ev)
             if side:
@@ -191,7 +192,9 @@ class DataParallel(torch.nn.Module):
             for w in getattr(self, "_works", []):
                 w.wait()           # (orders the compute stream after the collective; no host block)
             self._works = []
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            if getattr(self, "_comm_used", False):   # (an untouched stream stays off the hardware queues)
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                self._comm_used = False
         else:
             for lo, hi in todo:
                 p = lo
