@@ -240,7 +240,8 @@ def main():
     from ecgmm.parallel import DataParallel, flatten
 
     model, batch, labels, loss_fn = build(args, device)
-    flatten(model)
+    from ecgmm.parallel import reduction_order
+    flatten(model, order=reduction_order(model))   # (same layout on one rank and on eight)
     # ECGMM_FORCE_DDP=1 rehearses the multi-rank code path (hooks, comm stream, bucketed all-reduce) on one rank
     force_ddp = os.environ.get("ECGMM_FORCE_DDP") == "1"
     if force_ddp and world == 1 and not dist.is_initialized():

@@ -33,7 +33,9 @@ class FusedAdam(torch.optim.Optimizer):
         runs = []
         for gi, group in enumerate(self.param_groups):
             cur = None
-            for p in group["params"]:
+            # (address order, not registration order: the step is elementwise, and a flat buffer laid out in another
+            # order -- parallel.reduction_order -- still becomes one launch)
+            for p in sorted(group["params"], key=lambda t: t.data_ptr()):
                 if not p.requires_grad or p.grad is None:
                     continue   # no gradient yet: skipped like torch.optim.Adam does (never created here)
                 if p.dtype != torch.float32 or not p.is_contiguous():

@@ -14,10 +14,29 @@ import torch.distributed as dist
 
 
 
-def flatten(model, only_trainable=True):
+def reduction_order(model):
+    """Parameters in the order their gradients become final in the backward of the multimodal model: image encoder
+    fc + layer4, then layer3, then everything else (layer2, layer1, stem, the other encoders, the head).  With the flat
+    buffer laid out this way every stage group of DataParallel is ONE contiguous range, and what is left after the last
+    overlapped group -- reduced after the backward, nothing left to hide it behind -- is one range too: one collective
+    instead of two at the tail."""
+    enc = getattr(model, "image_encoder", None)
+    allp = list(model.parameters())
+    if enc is None or not all(hasattr(enc, a) for a in ("fc", "layer4", "layer3")):
+        return allp
+    first = list(enc.fc.parameters()) + list(enc.layer4.parameters())
+    second = list(enc.layer3.parameters())
+    taken = {id(p) for p in first + second}
+    return first + second + [p for p in allp if id(p) not in taken]
+
+
+def flatten(model, only_trainable=True, order=None):
     """Re-point every (trainable) parameter and its gradient at slices of two flat fp32 buffers.
-    Returns (flat_params, flat_grads).  Order = model.parameters() order."""
-    params = [p for p in model.parameters() if (p.requires_grad or not only_trainable)]
+    Returns (flat_params, flat_grads).  Order = model.parameters() order, or `order` (a permutation of them)."""
+    src = list(model.parameters()) if order is None else list(order)
+    if order is not None and sorted(map(id, src)) != sorted(map(id, model.parameters())):
+        raise ValueError("flatten: `order` must be a permutation of model.parameters()")
+    params = [p for p in src if (p.requires_grad or not only_trainable)]
     if not params:
         return None, None
     dev = params[0].device
@@ -53,7 +72,7 @@ class DataParallel(torch.nn.Module):
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         self.grad_scale = 1.0 / self.world
         if getattr(module, "_ecg_flat", None) is None:
-            flatten(module)
+            flatten(module, order=reduction_order(module))
         self.flat_p, self.flat_g, self._params, self._offs = module._ecg_flat
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self._pending = []
