@@ -65,7 +65,7 @@ class DataParallel(torch.nn.Module):
     with ``overlap=True``, during) backward.  Gradients are SUMMED; pass ``grad_scale=1/world`` to
     FusedAdam (``self.grad_scale``)."""
 
-    def __init__(self, module, process_group=None, bucket_mb=32, overlap=True, force=False):
+    def __init__(self, module, process_group=None, bucket_mb=64, overlap=True, force=False):
         super().__init__()
         self.module = module
         self.pg = process_group
