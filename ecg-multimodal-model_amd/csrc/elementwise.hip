@@ -26,7 +26,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const int slice = threadIdx.x >> 6;  // 16 row slices
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int r = slice; r < rows; r += 16) {
+    int r = slice;
+    for (; r + 48 < rows; r += 64) {   // four rows per trip: eight independent loads in flight (same summation order)
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* row = partial + (size_t)(r + 16 * u) * 2 * C;
+        a[u] = row[c];
+        b[u] = row[C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s1 += (double)a[u];
+        s2 += (double)b[u];
+      }
+    }
+    for (; r < rows; r += 16) {
       const float* row = partial + (size_t)r * 2 * C;
       s1 += (double)row[c];
       s2 += (double)row[C + c];
@@ -68,8 +83,17 @@ __global__ __launch_bounds__(1024) void rows_stage1_kernel(const float* __restri
   const int slice = threadIdx.x >> 6;
   const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
   double s = 0.0;
-  if (col < width)
-    for (int r = r0 + slice; r < r1; r += 16) s += (double)partial[(size_t)r * width + col];
+  if (col < width) {
+    int r = r0 + slice;
+    for (; r + 48 < r1; r += 64) {   // four independent loads per trip (same summation order)
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = partial[(size_t)(r + 16 * u) * width + col];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (double)a[u];
+    }
+    for (; r < r1; r += 16) s += (double)partial[(size_t)r * width + col];
+  }
   sh[slice][threadIdx.x & 63] = s;
   __syncthreads();
   if (slice == 0 && col < width) {
@@ -326,12 +350,28 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int r = slice; r < rows; r += 16) {
+  if (c < C) {
+    int r = slice;
+    for (; r + 48 < rows; r += 64) {   // (as bn_finalize_kernel: four rows per trip)
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* row = partial + (size_t)(r + 16 * u) * 2 * C;
+        a[u] = row[c];
+        b[u] = row[C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s1 += (double)a[u];
+        s2 += (double)b[u];
+      }
+    }
+    for (; r < rows; r += 16) {
       const float* row = partial + (size_t)r * 2 * C;
       s1 += (double)row[c];
       s2 += (double)row[C + c];
     }
+  }
   sh[0][slice][threadIdx.x & 63] = s1;
   sh[1][slice][threadIdx.x & 63] = s2;
   __syncthreads();
@@ -357,8 +397,17 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict_
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int slice = threadIdx.x >> 6;
   double s = 0.0;
-  if (c < C)
-    for (int r = slice; r < rows; r += 16) s += (double)partial[(size_t)r * C + c];
+  if (c < C) {
+    int r = slice;
+    for (; r + 48 < rows; r += 64) {   // four independent loads per trip (same summation order)
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = partial[(size_t)(r + 16 * u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (double)a[u];
+    }
+    for (; r < rows; r += 16) s += (double)partial[(size_t)r * C + c];
+  }
   sh[slice][threadIdx.x & 63] = s;
   __syncthreads();
   if (slice == 0 && c < C) {
