@@ -472,7 +472,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     int s = i % 7;
     int t = i / 7;
     int G = t % NG, co = t / NG;
-    for (int k = sl; k < nsplit; k += 16) acc += slab[((size_t)k * STEM_CO + co) * NK + G * 8 + s];
+    const float* src = slab + (size_t)co * NK + G * 8 + s;
+    const size_t stride = (size_t)STEM_CO * NK;
+    int k = sl;
+    for (; k + 48 < nsplit; k += 64) {   // four independent loads per trip (same summation order)
+      const float a0 = src[(size_t)k * stride], a1 = src[(size_t)(k + 16) * stride];
+      const float a2 = src[(size_t)(k + 32) * stride], a3 = src[(size_t)(k + 48) * stride];
+      acc += a0;
+      acc += a1;
+      acc += a2;
+      acc += a3;
+    }
+    for (; k < nsplit; k += 16) acc += src[(size_t)k * stride];
   }
   sh[sl][oi] = acc;
   __syncthreads();

@@ -656,6 +656,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   float s0 = 0.f, s1 = 0.f;
   if (i < per) {
     int k = grp;
+    for (; k + 12 < nsplit; k += 16) {   // four independent loads per trip (same two interleaved sums as below)
+      const float a0 = slab[(size_t)k * per + i], a1 = slab[(size_t)(k + 4) * per + i];
+      const float a2 = slab[(size_t)(k + 8) * per + i], a3 = slab[(size_t)(k + 12) * per + i];
+      s0 += a0;
+      s1 += a1;
+      s0 += a2;
+      s1 += a3;
+    }
     for (; k + 4 < nsplit; k += 8) {
       s0 += slab[(size_t)k * per + i];
       s1 += slab[(size_t)(k + 4) * per + i];
