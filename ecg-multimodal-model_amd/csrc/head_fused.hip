@@ -578,11 +578,31 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_weights_kernel(const float* __
     if (o < T2) {                       // dW2[c][j]
       const int c = o / CR, j = o - c * CR;
       dst = dw2 ? dw2 + o : nullptr;
-      if (dst) for (int n = sl; n < N; n += 4) acc += ds[(size_t)n * C + c] * h[(size_t)n * CR + j];
+      if (dst) {
+        int n = sl;
+        for (; n + 12 < N; n += 16) {   // four independent load pairs per trip (same summation order)
+          float a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a[u] = ds[(size_t)(n + 4 * u) * C + c]; b[u] = h[(size_t)(n + 4 * u) * CR + j]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += a[u] * b[u];
+        }
+        for (; n < N; n += 4) acc += ds[(size_t)n * C + c] * h[(size_t)n * CR + j];
+      }
     } else if (o < 2 * T2) {            // dW1[j][c]
       const int q = o - T2, j = q / C, c = q - j * C;
       dst = dw1 ? dw1 + q : nullptr;
-      if (dst) for (int n = sl; n < N; n += 4) acc += dh[(size_t)n * CR + j] * m[(size_t)n * C + c];
+      if (dst) {
+        int n = sl;
+        for (; n + 12 < N; n += 16) {
+          float a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a[u] = dh[(size_t)(n + 4 * u) * CR + j]; b[u] = m[(size_t)(n + 4 * u) * C + c]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += a[u] * b[u];
+        }
+        for (; n < N; n += 4) acc += dh[(size_t)n * CR + j] * m[(size_t)n * C + c];
+      }
     } else if (o < 2 * T2 + C) {        // db2[c]
       const int c = o - 2 * T2;
       dst = db2 ? db2 + c : nullptr;
