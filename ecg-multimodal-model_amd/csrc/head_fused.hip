@@ -563,59 +563,63 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_samples_kernel(const float* __
 }
 
 // dW2[c][j] = sum_n ds[n][c] h[n][j], db2[c] = sum_n ds[n][c], dW1[j][c] = sum_n dh[n][j] m[n][c], db1[j] = sum_n dh[n][j]
-// One output per 4 threads (sample slices n = s mod 4), folded in LDS in a fixed order.  Null outputs are skipped.
-__global__ __launch_bounds__(256) void se_mlp_bwd_weights_kernel(const float* __restrict__ ds, const float* __restrict__ dh,
-                                                                 const float* __restrict__ h, const float* __restrict__ m,
-                                                                 float* __restrict__ dw1, float* __restrict__ db1,
-                                                                 float* __restrict__ dw2, float* __restrict__ db2, int N,
-                                                                 int C, int CR) {
-  __shared__ float sh[4][64];
+// 64 outputs per 1024-thread block, the batch cut into 16 slices (n = s mod 16) with four independent load pairs per
+// trip, folded in LDS in a fixed order.  Null outputs are skipped.  (4 slices of 128 dependent L2 loads each: 26 us.)
+__global__ __launch_bounds__(1024) void se_mlp_bwd_weights_kernel(const float* __restrict__ ds, const float* __restrict__ dh,
+                                                                  const float* __restrict__ h, const float* __restrict__ m,
+                                                                  float* __restrict__ dw1, float* __restrict__ db1,
+                                                                  float* __restrict__ dw2, float* __restrict__ db2, int N,
+                                                                  int C, int CR) {
+  constexpr int NS = 16;
+  __shared__ float sh[NS][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
   const int T2 = C * CR, T = 2 * T2 + C + CR;
   float acc = 0.f;
   float* dst = nullptr;
+  // every output is sum_n a[n * sa + ia] * (b ? b[n * sb + ib] : 1)
+  const float *pa = nullptr, *pb = nullptr;
+  size_t sa = 0, sb = 0;
   if (o < T) {
     if (o < T2) {                       // dW2[c][j]
       const int c = o / CR, j = o - c * CR;
       dst = dw2 ? dw2 + o : nullptr;
-      if (dst) {
-        int n = sl;
-        for (; n + 12 < N; n += 16) {   // four independent load pairs per trip (same summation order)
-          float a[4], b[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { a[u] = ds[(size_t)(n + 4 * u) * C + c]; b[u] = h[(size_t)(n + 4 * u) * CR + j]; }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc += a[u] * b[u];
-        }
-        for (; n < N; n += 4) acc += ds[(size_t)n * C + c] * h[(size_t)n * CR + j];
-      }
+      pa = ds + c; sa = C; pb = h + j; sb = CR;
     } else if (o < 2 * T2) {            // dW1[j][c]
       const int q = o - T2, j = q / C, c = q - j * C;
       dst = dw1 ? dw1 + q : nullptr;
-      if (dst) {
-        int n = sl;
-        for (; n + 12 < N; n += 16) {
-          float a[4], b[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { a[u] = dh[(size_t)(n + 4 * u) * CR + j]; b[u] = m[(size_t)(n + 4 * u) * C + c]; }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc += a[u] * b[u];
-        }
-        for (; n < N; n += 4) acc += dh[(size_t)n * CR + j] * m[(size_t)n * C + c];
-      }
+      pa = dh + j; sa = CR; pb = m + c; sb = C;
     } else if (o < 2 * T2 + C) {        // db2[c]
       const int c = o - 2 * T2;
       dst = db2 ? db2 + c : nullptr;
-      if (dst) for (int n = sl; n < N; n += 4) acc += ds[(size_t)n * C + c];
+      pa = ds + c; sa = C;
     } else {                            // db1[j]
       const int j = o - 2 * T2 - C;
       dst = db1 ? db1 + j : nullptr;
-      if (dst) for (int n = sl; n < N; n += 4) acc += dh[(size_t)n * CR + j];
+      pa = dh + j; sa = CR;
     }
+  }
+  if (dst) {
+    int n = sl;
+    for (; n + 3 * NS < N; n += 4 * NS) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = pa[(size_t)(n + NS * u) * sa];
+        b[u] = pb ? pb[(size_t)(n + NS * u) * sb] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += a[u] * b[u];
+    }
+    for (; n < N; n += NS) acc += pa[(size_t)n * sa] * (pb ? pb[(size_t)n * sb] : 1.f);
   }
   sh[sl][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (sl == 0 && dst) *dst = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (sl == 0 && dst) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) t += sh[k][threadIdx.x];
+    *dst = t;
+  }
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -640,7 +644,7 @@ int ecg_se_mlp_bwd(const float* dg, const float* g, const float* h, const float*
   ECG_CHECK_LAUNCH("se_mlp_bwd_samples");
   if (dw1 || db1 || dw2 || db2) {
     const int T = 2 * C * CR + C + CR;
-    hipLaunchKernelGGL(se_mlp_bwd_weights_kernel, dim3((T + 63) / 64), dim3(256), 0, s, (const float*)ds, (const float*)dh, h,
+    hipLaunchKernelGGL(se_mlp_bwd_weights_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, (const float*)ds, (const float*)dh, h,
                        m, dw1, db1, dw2, db2, N, C, CR);
     ECG_CHECK_LAUNCH("se_mlp_bwd_weights");
   }
