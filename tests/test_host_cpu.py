@@ -207,3 +207,42 @@ def test_fused_adam_never_creates_gradients_cpu():
     assert opt._runs_valid()
     net[1].bias.grad = torch.zeros_like(net[1].bias)        # a parameter gains its gradient later: runs are re-planned
     assert not opt._runs_valid()
+
+
+def test_flat_buffer_in_reduction_order_keeps_stage_groups_contiguous_and_one_adam_run():
+    """parallel.reduction_order: [fc + layer4 | layer3 | everything else] -- every data-parallel stage group is one
+    contiguous range of the flat gradient buffer, the rest (reduced after the backward) is ONE range, parameters are still
+    views of the buffer, and FusedAdam (which plans in address order) still covers it with a single run."""
+    from ecgmm.config import Config
+    from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+    from ecgmm.optim import FusedAdam
+    from ecgmm.parallel import flatten, reduction_order
+    cfg = type("C", (Config,), {"clinical_input_dim": 16})
+    m = ECGMultimodalModel(cfg)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    order = reduction_order(m)
+    assert sorted(map(id, order)) == sorted(map(id, m.parameters()))
+    flat_p, flat_g = flatten(m, order=order)
+    _, _, params, offs = m._ecg_flat
+    enc = m.image_encoder
+    pos = {id(p): (o, o + p.numel()) for p, o in zip(params, offs)}
+
+    def span(mods):
+        ps = [p for mod in mods for p in mod.parameters()]
+        return min(pos[id(p)][0] for p in ps), max(pos[id(p)][1] for p in ps), sum((p.numel() + 3) // 4 * 4 for p in ps)
+
+    lo1, hi1, n1 = span([enc.fc, enc.layer4])
+    lo2, hi2, n2 = span([enc.layer3])
+    assert lo1 == 0 and hi1 - lo1 <= n1 and lo2 >= hi1 and hi2 - lo2 <= n2      # contiguous, in this order
+    rest_lo = min(pos[id(p)][0] for p in m.parameters() if not (lo1 <= pos[id(p)][0] < hi2))
+    assert rest_lo >= hi2                                                         # everything else behind them: one range
+    for k, v in m.state_dict().items():                                           # values unchanged, parameters are views
+        assert torch.equal(v, before[k])
+    p0 = next(iter(enc.layer4.parameters()))
+    o0 = pos[id(p0)][0]
+    assert p0.data_ptr() == flat_p.data_ptr() + 4 * o0 and p0.grad.data_ptr() == flat_g.data_ptr() + 4 * o0
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    opt._build_runs()
+    assert len(opt._runs) == 1 and opt._runs[0]["n"] == flat_p.numel() - (flat_p.numel() - max(e for _, e in pos.values()))
+    with pytest.raises(ValueError):
+        flatten(ECGMultimodalModel(cfg), order=order[:-1])
