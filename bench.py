@@ -81,8 +81,8 @@ PROF_KINDS = ["conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "stem_fwd", "s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # SURVEY 8d timing protocol: >= 20 warm-up, >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="multimodal", choices=list(FLOP_PER_SAMPLE))
@@ -157,6 +157,30 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+def cpu_model_name():
+    """CPU model string of this box (the CPU baseline states core count, CPU model and torch version)."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def latest_traffic_file():
+    """profiles/rNN_igemm_traffic.json of the highest round present (written by tools/final_profiles.sh), or None."""
+    import glob
+    import re as _re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_igemm_traffic.json")):
+        m = _re.search(r"r(\d+)_igemm_traffic\.json$", f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def cpu_baseline(seconds):
     """Reference CPU path (BASELINE config 1): oracle train step, batch 8, fp32, all host cores."""
     from oracle import ref_models as O
@@ -183,6 +207,7 @@ def cpu_baseline(seconds):
         if el > seconds or n >= 2000:
             break
     return {"value": round(B * n / el, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_name(), "torch": torch.__version__,
             "sample": f"{n} train steps of oracle.ECGMultimodalModel (torch {torch.__version__} CPU fp32), batch 8, "
                       f"3x224x224 + 5000-pt + 16-dim, CE + 0.1 var_loss, Adam"}
 
@@ -320,14 +345,18 @@ def main():
         if rc != 0 or ig_ms <= 0:
             return None
         # HBM traffic per launch from the rocprofv3 PMC passes of this same command (cannot be collected from
-        # inside the process): tools/final_profiles.sh -> profiles/r02_igemm_traffic.json (round-end code)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_igemm_traffic.json")
-        if args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and os.path.exists(tpath):
+        # inside the process): tools/final_profiles.sh -> profiles/rNN_igemm_traffic.json (round-end code).  It was
+        # measured on the headline configuration only -- unfrozen encoders, 224x224, batch 256, bf16 -- and is
+        # attached to no other run (null there: absent, not zero).
+        traffic = traffic_src = None
+        tpath = latest_traffic_file()
+        if (args.dtype == "bf16" and args.workload == "multimodal" and args.batch == 256 and tpath
+                and not args.freeze_encoders and args.image_hw.lower() == "224x224"):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"], 1)
+            traffic_src = os.path.relpath(tpath, ROOT)
         ach = ig_fl / (ig_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": ("igemm_kernel<bf16> + conv_halo_kernel (conv fwd + dgrad)" if args.dtype == "bf16" else "igemm_kernel<f32> (conv fwd + dgrad)"), "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(ig_by / max(ig_n, 1), 1), "launches": ig_n,
                 "avg_launch_ms": round(ig_ms / max(ig_n, 1), 4), "flop_per_launch": round(ig_fl / max(ig_n, 1), 1),
                 "by_kind": {k: {"ms_per_step": round(v["ms"] / nsteps, 3),
@@ -348,10 +377,11 @@ def main():
             cfg_obj.overlap_encoders = False
         step(); fence()
         L.check(lib.ecgmm_prof_enable(1), "prof_enable")
-        for _ in range(args.steps):
+        n_serial = min(args.steps, 20)    # (~110 event pairs per step; csrc/prof.hip holds 8192)
+        for _ in range(n_serial):
             step()
         fence()
-        roof_serial = collect_roofline(args.steps, "same launches, serialized on one stream (overlap off), untimed extra pass")
+        roof_serial = collect_roofline(n_serial, f"same launches, serialized on one stream (overlap off), untimed extra pass of {n_serial} steps")
         lib.ecgmm_prof_enable(0)
         lib.ecgmm_side_wgrad(1)
         if cfg_obj is not None:

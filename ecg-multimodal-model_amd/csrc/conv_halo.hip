@@ -653,6 +653,29 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   }
 }
 
+// Workgroups per channel tile of a launch (= partial rows a wg_rows launch writes per channel tile): one persistent
+// workgroup per CU -- of at most ECGMM_HALO_CUS CUs -- shared out over the ntn channel tiles, never more than the pixel
+// tiles.  The ONE place this is computed: the launch and ecg_conv_halo_rows() (whose caller sizes the read of a row
+// buffer another launch fills) must agree for every setting of the cap.
+int g_halo_cu_cap = -1;  // -1: read ECGMM_HALO_CUS at first use; <= 0 after that: no cap
+int halo_gk(int ntn, int ntm) {
+  static int ncu[16] = {0};
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16) {
+    if (ncu[dev] == 0) {
+      hipDeviceProp_t prop;
+      ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    cus = ncu[dev];
+  }
+  if (g_halo_cu_cap < 0) { const char* e = getenv("ECGMM_HALO_CUS"); g_halo_cu_cap = e ? atoi(e) : 0; if (g_halo_cu_cap < 0) g_halo_cu_cap = 0; }
+  if (g_halo_cu_cap > 0 && cus > g_halo_cu_cap) cus = g_halo_cu_cap;
+  int Gk = cus / (ntn < 1 ? 1 : ntn);
+  if (Gk > ntm) Gk = ntm;
+  return Gk < 1 ? 1 : Gk;
+}
+
 template <int BN, int RS, int MODE, bool NCS1 = false>
 int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   using C = HaloCfg<BN>;
@@ -665,21 +688,11 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
       ECG_FAIL(ECGMM_ERR_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", C::LDS);
     attr_set[dev] = true;
   }
-  static int ncu[16] = {0};
-  if (dev >= 0 && dev < 16 && ncu[dev] == 0) {
-    hipDeviceProp_t prop;
-    ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
   HaloParams q = p;
   q.ntm = p.M / HBM_;
   q.ntn = p.Cd / BN;
-  static const int cu_cap = [] { const char* e = getenv("ECGMM_HALO_CUS"); return e ? atoi(e) : 1 << 20; }();
-  int cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
-  if (cus > cu_cap) cus = cu_cap;
   // persistent: one workgroup per CU; Gk workgroups per channel tile (each walks pixel tiles k, k + Gk, ...)
-  int Gk = cus / q.ntn;
-  if (Gk > q.ntm) Gk = q.ntm;
-  if (Gk < 1) Gk = 1;
+  const int Gk = halo_gk(q.ntn, q.ntm);
   *rows_out = Gk;
   hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1>), dim3(Gk * q.ntn), dim3(HTHREADS), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
@@ -693,6 +706,12 @@ int g_halo_enabled = -1;  // read once from ECGMM_CONV_HALO: 0 = off, 1 = where 
 // Runtime switch (A/B against conv_igemm from one process: tools/conv_bench.py): 0 = never take the halo kernel.
 extern "C" int ecgmm_conv_halo_enable(int on) {
   g_halo_enabled = on < 0 ? 0 : on > 2 ? 2 : on;
+  return 0;
+}
+
+// Cap on the CUs (= persistent workgroups) a halo launch occupies: 0 = all (default).  Start-up value: ECGMM_HALO_CUS.
+extern "C" int ecgmm_conv_halo_cus(int cus) {
+  g_halo_cu_cap = cus < 0 ? 0 : cus;
   return 0;
 }
 
@@ -723,18 +742,7 @@ bool ecg_conv_halo_ok(int dtype, int mode, const ConvGeom& g) {
 int ecg_conv_halo_rows(int mode, const ConvGeom& g) {
   const int Cd = mode == 0 ? g.Cout : g.Cin;
   const int ntn = Cd > 64 ? Cd / 128 : 1, ntm = g.N * g.H * g.W / HBM_;
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  static int ncu_cache[16] = {0};
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16) {
-    if (ncu_cache[dev] == 0)
-      ncu_cache[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    cus = ncu_cache[dev];
-  }
-  int Gk = cus / ntn;
-  if (Gk > ntm) Gk = ntm;
-  return Gk < 1 ? 1 : Gk;
+  return halo_gk(ntn, ntm);
 }
 
 int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst, const float* bias,

@@ -195,9 +195,18 @@ class ECGMultimodalModel(nn.Module):
             print(f"Unexpected keys: {unexpected}")
 
     def load_pretrained_image_encoder(self, weight_path: str, load_fc: bool = False):
+        """PMB:356-384: the reference loads the file into a temporary resnet18 whose fc has the checkpoint's width, so a
+        tensor of the wrong shape RAISES there (PMB:369-371) -- it does here too; only `fc.*` is dropped when
+        ``load_fc`` is false (PMB:378), and keys the encoder does not have are ignored (strict=False)."""
         saved_state = torch.load(weight_path, map_location="cpu")
         current = self.image_encoder.state_dict()
-        new_state = {k: v for k, v in saved_state.items() if k in current and v.shape == current[k].shape}
+        new_state = {k: v for k, v in saved_state.items() if k in current}
+        # (checked on every matching key, `fc.*` included even when it is dropped below: the reference's temporary
+        # resnet has an fc of this model's image_dim and load_state_dict raises on it first)
+        bad = [(k, tuple(v.shape), tuple(current[k].shape)) for k, v in new_state.items() if v.shape != current[k].shape]
+        if bad:
+            raise RuntimeError("load_pretrained_image_encoder: size mismatch for " +
+                               ", ".join(f"{k}: checkpoint {a} vs model {b}" for k, a, b in bad))
         if not load_fc:
             new_state = {k: v for k, v in new_state.items() if not k.startswith("fc.")}
         current.update(new_state)

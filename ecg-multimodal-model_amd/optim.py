@@ -50,7 +50,10 @@ class FusedAdam(torch.optim.Optimizer):
                 gap = p.data_ptr() - cur["p_end"] if cur is not None else -1
                 # flatten() pads tensors to 16 B: a gap of <= 12 B inside the flat buffers is padding whose
                 # gradient stays zero, so it can ride along in the same launch
-                if cur is not None and 0 <= gap <= 12 and gap % 4 == 0 and g.data_ptr() - cur["g_end"] == gap:
+                # (one step counter per run = per launch: a parameter whose own count differs -- it gained its gradient
+                # later than its neighbours -- starts a new run, so its bias correction is torch's per-parameter one)
+                if (cur is not None and 0 <= gap <= 12 and gap % 4 == 0 and g.data_ptr() - cur["g_end"] == gap
+                        and st["step"] == cur["step"]):
                     cur["offs"].append(cur["n"] + gap // 4)
                     cur["n"] += gap // 4 + n
                     cur["p_end"] = p.data_ptr() + n * 4
@@ -58,13 +61,12 @@ class FusedAdam(torch.optim.Optimizer):
                     cur["params"].append(p)
                 else:
                     cur = dict(group=gi, p=p.data_ptr(), g=g.data_ptr(), n=n, p_end=p.data_ptr() + n * 4,
-                               g_end=g.data_ptr() + n * 4, params=[p], offs=[0])
+                               g_end=g.data_ptr() + n * 4, params=[p], offs=[0], step=st["step"])
                     runs.append(cur)
         for r in runs:
             dev = r["params"][0].device
             r["m"] = torch.zeros(r["n"], device=dev, dtype=torch.float32)
             r["v"] = torch.zeros(r["n"], device=dev, dtype=torch.float32)
-            r["step"] = 0
         self._runs = runs
 
     def _runs_valid(self):
@@ -93,14 +95,13 @@ class FusedAdam(torch.optim.Optimizer):
                 for r in old:
                     for p, off in zip(r["params"], r["offs"]):
                         n = p.numel()
-                        prev[id(p)] = (r["m"][off:off + n], r["v"][off:off + n], r["step"])
+                        prev[id(p)] = (r["m"][off:off + n], r["v"][off:off + n])
                 for r in self._runs:
                     for p, off in zip(r["params"], r["offs"]):
                         n = p.numel()
                         if id(p) in prev:
                             r["m"][off:off + n].copy_(prev[id(p)][0])
                             r["v"][off:off + n].copy_(prev[id(p)][1])
-                            r["step"] = prev[id(p)][2]
         # a gradient buffer that some earlier backward wrote but the one since the last zero_grad()/step() did
         # not holds a stale value: zero it (what torch's zero_grad(set_to_none=False) would have left there)
         for g in self.param_groups:

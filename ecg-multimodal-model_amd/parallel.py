@@ -177,6 +177,18 @@ class DataParallel(torch.nn.Module):
                 dist.all_reduce(self.flat_g[pos:end], op=dist.ReduceOp.SUM, group=self.pg)
                 pos = end
 
+    def _remaining(self, done):
+        """Ranges of the flat buffer NOT covered by `done` (the ranges the stage hooks have shipped), in address order."""
+        total = self.flat_g.numel()
+        todo, pos = [], 0
+        for lo, hi in sorted(done):
+            if lo > pos:
+                todo.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < total:
+            todo.append((pos, total))
+        return todo
+
     def prepare_backward(self):
         self._done_ranges = []
         self._works = []
@@ -186,19 +198,20 @@ class DataParallel(torch.nn.Module):
         stream wait for the comm stream."""
         if self.world == 1 and not self.force:
             return
-        done = sorted(getattr(self, "_done_ranges", []))
-        total = self.flat_g.numel()
-        todo, pos = [], 0
-        for lo, hi in done:
-            if lo > pos:
-                todo.append((pos, lo))
-            pos = max(pos, hi)
-        if pos < total:
-            todo.append((pos, total))
+        todo = self._remaining(getattr(self, "_done_ranges", []))
         if self.overlap:
             if self._tail_on_compute:
-                # (the backward has returned: autograd has already joined every stream it used to the compute stream,
-                # and the last stage group's plan call joined the weight-gradient side stream)
+                # The backward has returned: autograd has joined the streams its nodes ran on, and the last stage group's
+                # plan call joined the weight-gradient side stream.  The tail collective reads gradients that Functions
+                # wrote straight into the flat buffer (they return None for parameters, so autograd's own leaf-stream
+                # sync does not know about those writes): order it EXPLICITLY after the model's encoder side stream and
+                # the library's weight-gradient stream -- two event waits that have normally fired already.
+                cur = torch.cuda.current_stream()
+                enc_side = getattr(self.module, "_side_stream", None)
+                if enc_side is not None:
+                    cur.wait_stream(enc_side)
+                from .hip import lib as L
+                L.check(L.lib().ecgmm_side_wait(cur.cuda_stream), "side_wait")
                 for lo, hi in todo:
                     p = lo
                     while p < hi:

@@ -159,6 +159,9 @@ int ecgmm_conv_stats_rows(int64_t out_pixels);
  * kernel (csrc/conv_halo.hip) instead of the general implicit-GEMM one: mode 0 = never, 1 = for the shapes it is
  * faster on (default), 2 = wherever it is applicable (A/B timing, tests).  Start-up value: ECGMM_CONV_HALO=0|1|2. */
 int ecgmm_conv_halo_enable(int on);
+/* Cap on the CUs (one persistent workgroup each) a halo-kernel launch occupies; 0 = all of them (default).  The partial-row
+ * counts of its fused BatchNorm reductions follow the cap.  Start-up value: ECGMM_HALO_CUS. */
+int ecgmm_conv_halo_cus(int cus);
 /* Weight gradients of the same stride-1 3x3 / 1x3 bf16 convolutions keep their x operand in an LDS ring of pixel rows
  * (wgrad_ring_kernel, csrc/conv_wgrad.hip) instead of one gathered tile per filter tap: 0 = never, 1 = for the shapes
  * it is faster on (default), 2 = wherever applicable (A/B, tests).  Start-up value: ECGMM_WGRAD_RING=0|1|2. */

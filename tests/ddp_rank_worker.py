@@ -22,7 +22,7 @@ def main():
     from ecgmm.hip import functional as HF
     from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
     from ecgmm.optim import FusedAdam
-    from ecgmm.parallel import DataParallel, flatten
+    from ecgmm.parallel import DataParallel, flatten, reduction_order
     from oracle import fill
 
     def build(prefix):
@@ -40,7 +40,7 @@ def main():
 
     # every rank starts from DIFFERENT parameters: the wrapper must broadcast rank 0's
     model = build("mm." if rank == 0 else f"other{rank}.")
-    flatten(model)
+    flatten(model, order=reduction_order(model))      # the layout bench.py uses (stage groups = contiguous ranges)
     ddp = DataParallel(model)
     opt = FusedAdam(model.parameters(), lr=1e-3, grad_scale=ddp.grad_scale)
     opt.zero_grad()
@@ -55,7 +55,7 @@ def main():
     acc = None
     for r in range(world):
         ref = build("mm.")
-        _, g = flatten(ref)
+        _, g = flatten(ref, order=reduction_order(ref))
         s = slice(r * per, (r + 1) * per)
         o = ref(img[s], sig[s], clin[s])
         (HF.cross_entropy(o[3], lab[s]) + 0.1 * o[4]).backward()

@@ -56,7 +56,10 @@ def _run_gpu(make_net, cd, inputs, loss_of):
     return res
 
 
-def _check(make_ref, make_net, inputs, loss_of, keys, tol_grad_fp32):
+def _check(make_ref, make_net, inputs, loss_of, keys, tol_grad_fp32, bf16_logit_abs, bf16_grad_rel):
+    """bf16_logit_abs / bf16_grad_rel: ABSOLUTE ceilings of the bf16 compute path beside the autocast-relative bar --
+    max |logit - fp32 oracle logit| over the batch, and the largest relative L2 error of the listed gradients (set at
+    about twice what the shipped kernels measure on MI355X; the measured values are printed)."""
     l32, loss32, g32 = _run_ref(make_ref, inputs, loss_of, False)
     # ---- fp32 compute path vs the fp32 oracle
     lg, lossg, gg = _run_gpu(make_net, "fp32", inputs, loss_of)
@@ -72,6 +75,13 @@ def _check(make_ref, make_net, inputs, loss_of, keys, tol_grad_fp32):
     lb, lossb, gb = _run_gpu(make_net, "bf16", inputs, loss_of)
     print("bf16 logits rel. error: HIP %.4f, torch autocast %.4f" % (rel_err(lb, l32), rel_err(l16, l32)))
     print("bf16 gradient rel. errors (HIP, torch autocast):", {k: (round(rel_err(gb[k], g32[k]), 4), round(rel_err(g16[k], g32[k]), 4)) for k in keys})
+    abs_hip, abs_ac = float((lb - l32).abs().max()), float((l16 - l32).abs().max())
+    worst = max(rel_err(gb[k], g32[k]) for k in keys)
+    print("bf16 ABSOLUTE errors: max |logit - oracle| HIP %.5f (ceiling %.3g; torch autocast %.5f), |loss - oracle| %.5f, "
+          "worst gradient rel. error %.4f (ceiling %.3g)" % (abs_hip, bf16_logit_abs, abs_ac, abs(lossb - loss32), worst,
+                                                            bf16_grad_rel))
+    assert abs_hip < bf16_logit_abs, abs_hip
+    assert worst < bf16_grad_rel, worst
     assert rel_err(lb, l32) < 1.3 * rel_err(l16, l32) + 0.02
     assert abs(lossb - loss32) < 0.05 * max(1.0, abs(loss32))
     bad = {k: (rel_err(gb[k], g32[k]), rel_err(g16[k], g32[k])) for k in keys
@@ -100,7 +110,7 @@ def test_cfg3_full_multimodal_batch256_vs_oracle():
             "image_encoder.layer4.1.conv2.weight", "image_encoder.fc.weight", "signal_encoder.initial.0.weight",
             "signal_encoder.layer3.conv2.weight", "clinical_encoder.0.weight", "fusion_classifier.0.weight",
             "attention_fusion.weights"]
-    _check(make_ref, make_net, (img, sig, clin), loss_of, keys, 1e-2)
+    _check(make_ref, make_net, (img, sig, clin), loss_of, keys, 1e-2, 5e-2, 0.6)
 
 
 def test_cfg2_image_only_batch128_vs_oracle():
@@ -120,7 +130,7 @@ def test_cfg2_image_only_batch128_vs_oracle():
 
     keys = ["image_encoder.conv1.weight", "image_encoder.layer1.0.conv1.weight", "image_encoder.layer3.0.conv1.weight",
             "image_encoder.layer4.1.conv2.weight", "image_encoder.fc.weight", "image_encoder.fc.bias"]
-    _check(make_ref, make_net, (img,), loss_of, keys, 1e-2)
+    _check(make_ref, make_net, (img,), loss_of, keys, 1e-2, 5e-2, 0.6)
 
 
 def test_cfg5_signal12_batch512_focal_vs_oracle():
@@ -142,4 +152,4 @@ def test_cfg5_signal12_batch512_focal_vs_oracle():
 
     keys = ["initial.0.weight", "layer1.conv1.weight", "layer2.downsample.0.weight", "layer3.conv2.weight",
             "layer3.se.fc.0.weight", "classifier.1.weight", "classifier.4.weight"]
-    _check(make_ref, make_net, (x,), loss_of, keys, 1e-2)
+    _check(make_ref, make_net, (x,), loss_of, keys, 1e-2, 5e-2, 0.6)

@@ -246,3 +246,92 @@ def test_flat_buffer_in_reduction_order_keeps_stage_groups_contiguous_and_one_ad
     assert len(opt._runs) == 1 and opt._runs[0]["n"] == flat_p.numel() - (flat_p.numel() - max(e for _, e in pos.values()))
     with pytest.raises(ValueError):
         flatten(ECGMultimodalModel(cfg), order=order[:-1])
+
+
+@pytest.mark.parametrize("groups", ["3", "2"])
+def test_stage_hook_ranges_cover_the_flat_buffer_exactly_once(groups, monkeypatch):
+    """on the REAL model's parameter list, the gradient ranges DataParallel's backward-stage hooks ship
+    early plus what reduce_gradients() ships afterwards cover the flat buffer exactly once (no element reduced twice --
+    a double all-reduce would multiply that gradient by the world size -- and none left out), for both ECGMM_DDP_GROUPS
+    settings; every range holds exactly the parameters of the encoder stages whose backward has finished by then."""
+    from ecgmm.config import Config
+    from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+    from ecgmm.parallel import DataParallel, flatten, reduction_order
+    monkeypatch.setenv("ECGMM_DDP_GROUPS", groups)
+    cfg = type("C", (Config,), {"clinical_input_dim": 16})
+    m = ECGMultimodalModel(cfg)
+    flatten(m, order=reduction_order(m))
+    ddp = DataParallel(m)                 # world 1, CPU: no process group needed; hooks are installed by hand below
+    ddp._install_hooks()
+    enc = m.image_encoder
+    spec = enc._spec
+    assert spec.stage_hook is not None and spec.stage_groups[0][0] == 0 and spec.stage_groups[-1][1] == spec.n_stages
+    assert all(a[1] == b[0] for a, b in zip(spec.stage_groups, spec.stage_groups[1:]))    # stages 0..9, each once
+    _, _, params, offs = m._ecg_flat
+    span = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(params, offs)}
+    owners = ([[enc.fc, enc.layer4], [enc.layer3], [enc.layer2, enc.layer1, enc.conv1, enc.bn1]] if groups == "3"
+              else [[enc.fc, enc.layer4], [enc.layer3, enc.layer2, enc.layer1, enc.conv1, enc.bn1]])
+    assert len(ddp._enc_ranges) == len(owners) == len(spec.stage_groups)
+    for (lo, hi), mods in zip(ddp._enc_ranges, owners):
+        mine = {id(p) for mod in mods for p in mod.parameters()}
+        inside = {i for i, (a, b) in span.items() if a >= lo and b <= hi}
+        assert inside == mine and sum(b - a for i, (a, b) in span.items() if i in mine) == hi - lo
+    # what the hooks ship early (all groups but the last with ECGMM_DDP_TAIL_ON_COMPUTE=1, the default) + the remainder
+    ddp.prepare_backward()
+    shipped = []
+    ddp._launch = lambda lo, hi, side=False: shipped.append((lo, hi))
+    for gi in range(len(owners)):
+        ddp._stage_hook(spec, gi)
+    assert len(shipped) == len(owners) - 1
+    pieces = sorted(shipped + ddp._remaining(ddp._done_ranges))
+    assert pieces[0][0] == 0 and pieces[-1][1] == ddp.flat_g.numel()
+    assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))                          # disjoint and gap-free
+    assert len(ddp._remaining(ddp._done_ranges)) == 1                                     # ONE tail collective
+    spec.stage_hook = spec.stage_groups = None
+
+
+def test_fused_adam_keeps_one_step_count_per_parameter_cpu():
+    """a parameter that gains its gradient later than its neighbours must not inherit their step count (its
+    first bias correction would be off by ~3x): it starts a run of its own."""
+    from ecgmm.optim import FusedAdam
+    from ecgmm.parallel import flatten
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))
+    flatten(net)
+    late = net[1].weight
+    late.grad = None
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    opt._build_runs()
+    for r in opt._runs:                      # what step() records after two updates
+        for p in r["params"]:
+            opt.state[p]["step"] = 2
+    late.grad = late._ecg_grad_view
+    assert not opt._runs_valid()
+    opt._build_runs()
+    steps = {id(p): r["step"] for r in opt._runs for p in r["params"]}
+    assert steps[id(late)] == 0 and steps[id(net[0].weight)] == 2 and steps[id(net[1].bias)] == 2
+    assert sum(len(r["params"]) for r in opt._runs) == 4 and len(opt._runs) == 3
+
+
+def test_pretrained_loaders_follow_the_reference(tmp_path):
+    """PMB:309-322 / :356-384: the signal loader drops `classifier.4*` unless load_fc, strict=False; the image loader
+    drops `fc.*` unless load_fc and RAISES on a tensor of the wrong shape (the reference loads through a temporary
+    resnet18, whose load_state_dict raises)."""
+    from ecgmm.config import Config
+    from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
+    m = ECGMultimodalModel(type("C", (Config,), {"clinical_input_dim": 16}))
+    sd = {k: torch.full_like(v, 0.25) if v.is_floating_point() else v.clone() for k, v in m.image_encoder.state_dict().items()}
+    torch.save(sd, tmp_path / "img.pth")
+    fc_before = m.image_encoder.fc.weight.clone()
+    m.load_pretrained_image_encoder(str(tmp_path / "img.pth"), load_fc=False)
+    assert float(m.image_encoder.layer3[1].conv2.weight.mean()) == 0.25 and torch.equal(m.image_encoder.fc.weight, fc_before)
+    m.load_pretrained_image_encoder(str(tmp_path / "img.pth"), load_fc=True)
+    assert float(m.image_encoder.fc.weight.mean()) == 0.25
+    sd["layer1.0.conv1.weight"] = torch.zeros(64, 32, 3, 3)
+    torch.save(sd, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_pretrained_image_encoder(str(tmp_path / "bad.pth"))
+    sd = {k: torch.full_like(v, 0.5) if v.is_floating_point() else v.clone() for k, v in m.signal_encoder.state_dict().items()}
+    torch.save(sd, tmp_path / "sig.pth")
+    last = m.signal_encoder.classifier[4].weight.clone()
+    m.load_pretrained_signal_encoder(str(tmp_path / "sig.pth"))
+    assert float(m.signal_encoder.layer2.conv1.weight.mean()) == 0.5 and torch.equal(m.signal_encoder.classifier[4].weight, last)

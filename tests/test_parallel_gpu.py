@@ -11,7 +11,7 @@ import torch.distributed as dist
 from ecgmm.config import Config
 from ecgmm.hip import functional as HF
 from ecgmm.multimodal_paper_modal_balance import ECGMultimodalModel
-from ecgmm.parallel import DataParallel, flatten
+from ecgmm.parallel import DataParallel, flatten, reduction_order
 from oracle import fill
 
 from .util import DEV, dev
@@ -33,7 +33,7 @@ def _model(cd):
 def test_stage_hooked_backward_equals_plain_backward(cd):
     img, sig, clin, lab = (dev(t) for t in fill.synthetic_batch(8, salt=11))
     plain = _model(cd)
-    _, g_plain = flatten(plain)
+    _, g_plain = flatten(plain, order=reduction_order(plain))   # bench.py's layout
     out = plain(img, sig, clin)
     (HF.cross_entropy(out[3], lab) + 0.1 * out[4]).backward()
     torch.cuda.synchronize()
@@ -47,7 +47,7 @@ def test_stage_hooked_backward_equals_plain_backward(cd):
         created = True
     try:
         model = _model(cd)
-        flatten(model)
+        flatten(model, order=reduction_order(model))
         ddp = DataParallel(model, force=True)
         assert ddp.overlap and model.image_encoder._spec.stage_hook is not None
         for _ in range(2):                       # second pass: the side-stream events are reused across steps

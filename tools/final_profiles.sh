@@ -16,7 +16,8 @@ B="python3 $R/bench.py --steps 2 --warmup 1 --no-prof --no-cpu-baseline --serial
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- $B > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- $B > $O/pmc_write.log 2>&1 || exit 1
 python3 $R/tools/roofline_traffic.py $O/pmc_fetch $O/pmc_write $O/igemm_traffic.json || exit 1
-cp $O/igemm_traffic.json $R/profiles/r02_igemm_traffic.json
+# (the file is pulled back with gpurun_out/final/ and committed from there: tools/pull_profiles.sh rNN vK copies it to
+# profiles/rNN_igemm_traffic.json, which bench.py reads as roofline.traffic -- the lease-side profiles/ does not come back)
 python3 $R/tools/pmc_kernels.py $O/pmc_fetch > $O/pmc_by_kernel.txt 2>&1; python3 $R/tools/pmc_kernels.py $O/pmc_write >> $O/pmc_by_kernel.txt 2>&1
 echo pmc-done
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || exit 1
