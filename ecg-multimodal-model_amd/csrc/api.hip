@@ -65,6 +65,22 @@ int ecgmm_stem_fwd(int dtype, const float* x, const void* packed, const float* b
                    int Cin, int H, int W, int R, void* stream) {
   return ecg_stem_fwd(dtype, x, packed, bias, y, stats, N, Cin, H, W, R, S_(stream));
 }
+int ecgmm_stem_stats_only_rows(int N, int Cin, int H, int W, int R) { return ecg_stem_stats_only_rows(N, Cin, H, W, R); }
+int ecgmm_stem_stats_only(int dtype, const float* x, const void* packed, const float* bias, float* stats, int N, int Cin,
+                          int H, int W, int R, void* stream) {
+  return ecg_stem_stats_only(dtype, x, packed, bias, stats, N, Cin, H, W, R, S_(stream));
+}
+int ecgmm_stem_pool_fwd(const float* x, const void* packed, const float* coef, void* pooled, uint8_t* idx, int N, int Cin,
+                        int H, int W, void* stream) {
+  return ecg_stem_pool_fwd(x, packed, coef, pooled, idx, N, Cin, H, W, S_(stream));
+}
+size_t ecgmm_stem_pool_bwd_workspace(int N, int Cin, int H, int W) { return ecg_stem_pool_bwd_workspace(N, Cin, H, W); }
+int ecgmm_stem_pool_bwd(const float* x, const void* packed, const float* coef, const float* gamma, const void* dp,
+                        const void* pooled, const uint8_t* idx, float* dgamma, float* dbeta, float* dw_oihw, void* ws,
+                        size_t ws_bytes, int N, int Cin, int H, int W, void* stream) {
+  return ecg_stem_pool_bwd(x, packed, coef, gamma, dp, pooled, idx, dgamma, dbeta, dw_oihw, ws, ws_bytes, N, Cin, H, W,
+                           S_(stream));
+}
 size_t ecgmm_stem_bwd_weight_workspace(int N, int Cin, int H, int W, int R) {
   return ecg_stem_wgrad_workspace(N, Cin, H, W, R);
 }

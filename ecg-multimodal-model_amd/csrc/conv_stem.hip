@@ -103,7 +103,11 @@ __device__ __forceinline__ int stem_xcd_order() {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <typename T, int R>
+// STATS_ONLY (round 3, the recomputing stem: conv_stem_fused.hip): the BatchNorm partial sums are all this pass is for --
+// no output store, and the sums stay in registers across the workgroup's images (a workgroup keeps one tile position):
+// one set of four statistics rows per WORKGROUP, written at the end, instead of one per tile (128 DPP adds per
+// wave-tile and 13x the rows for the finalize to fold).
+template <typename T, int R, bool STATS_ONLY = false>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TH = StemDims<R>::TH, TW = StemDims<R>::TW, PH = StemDims<R>::PH, PWS = StemDims<R>::PWS;
@@ -169,6 +173,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   // Two patch buffers: the next image's patch is fetched into registers at the top of a tile and written to the
   // OTHER buffer between this tile's MFMA loop and its epilogue, so the wait for those loads does not also wait for
   // the previous epilogue's output stores (stores and loads share vmcnt), and a tile needs one barrier, not two.
+  float ws1[STATS_ONLY ? 4 : 1][4], ws2[STATS_ONLY ? 4 : 1][4];   // STATS_ONLY: per-lane sums over all of the workgroup's tiles
+  if (STATS_ONLY) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ws1[a][j] = ws2[a][j] = 0.f;
+  }
   int n = slot;
   if (n < p.N) {
     stem_fetch_image_patch<R>(p, poff, pre, n);
@@ -239,6 +250,22 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }
 
   if (has_next) stem_store_slots<T, R>(patch0 + (cur ^ 1) * PB, pre);
+  if constexpr (STATS_ONLY) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (okb[b]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = p.bias ? acc[a][b][j] + p.bias[a * 16 + fq * 4 + j] : acc[a][b][j];
+            ws1[a][j] += v;
+            ws2[a][j] += v * v;
+          }
+        }
+    __syncthreads();
+    continue;
+  }
   // epilogue: lane = pixel fr of segment b, channels a*16 + fq*4 + j
   T* yimg = (T*)p.y + (size_t)n * p.OH * p.OW * STEM_CO;
   const int tile = n * tpi + pos;
@@ -314,6 +341,23 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }  // channel-tile pairs
   __syncthreads();  // the other buffer is complete; everyone is done reading this one
   }  // image loop
+  if constexpr (STATS_ONLY) {
+    // rows [blockIdx.x * 4 + wave][2][64]: 16-lane DPP sums once per workgroup
+    float* srow = p.stats + ((size_t)blockIdx.x * 4 + wave) * 2 * STEM_CO;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x4 r1, r2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r1[j] = row16_sum(ws1[a][j]);
+        r2[j] = row16_sum(ws2[a][j]);
+      }
+      if (fr == 0) {
+        *reinterpret_cast<f32x4*>(srow + a * 16 + fq * 4) = r1;
+        *reinterpret_cast<f32x4*>(srow + STEM_CO + a * 16 + fq * 4) = r2;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -593,6 +637,44 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   }
   ecg_prof_end(stream);
   ECG_CHECK_LAUNCH("stem_fwd");
+  return 0;
+}
+
+// Statistics-only pass of the recomputing stem (conv_stem_fused.hip): rows = 4 per workgroup.
+static int stem_stats_grid(int N, int tpi) {
+  int nslots = 2048 / tpi;
+  nslots = nslots < 1 ? 1 : (nslots > N ? N : nslots);
+  return tpi * nslots;
+}
+int ecg_stem_stats_only_rows(int N, int Cin, int H, int W, int R) {
+  StemShape s;
+  if (stem_shape(Cin, H, W, R, s)) return -1;
+  return 4 * stem_stats_grid(N, s.tiles_h * s.tiles_w);
+}
+int ecg_stem_stats_only(int dtype, const float* x, const void* wpk, const float* bias, float* stats, int N, int Cin,
+                        int H, int W, int R, hipStream_t stream) {
+  if (dtype != ECGMM_BF16) ECG_FAIL(ECGMM_ERR_DTYPE, "stem statistics-only pass: bf16 only");
+  StemShape s;
+  ECG_TRY(stem_shape(Cin, H, W, R, s));
+  StemParams p;
+  fill_params(p, s, N, Cin, H, W, R);
+  p.x = x; p.wpk = wpk; p.bias = bias; p.stats = stats;
+  const int WS = s.KP + 8;
+  size_t lds = align_up((size_t)STEM_CO * WS * 2, 16) + 2 * stem_patch_buffer_bytes(R, 2);
+  dim3 grid(stem_stats_grid(N, s.tiles_h * s.tiles_w));
+  ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, 4.0 * N * Cin * H * W, stream);
+  if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7, true>), grid, dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1, true>), grid, dim3(256), lds, stream, p);
+  ecg_prof_end(stream);
+  ECG_CHECK_LAUNCH("stem_stats_only");
+  return 0;
+}
+
+// fold of a [rows][64][NG * 8] slab of weight-gradient partial tiles into the OIHW gradient (also used by conv_stem_fused.hip)
+int ecg_stem_wgrad_reduce(const float* slab, float* grad, int rows, int NG, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(STEM_CO * NG * 7, 16)), dim3(256), 0, stream, slab, grad, rows, NG,
+                     accumulate);
+  ECG_CHECK_LAUNCH("stem_wgrad_reduce");
   return 0;
 }
 

@@ -1272,6 +1272,39 @@ static void pool_bwd_launch(const void* dp, const void* pooled, const unsigned c
   if (dbias) hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, (const float*)partial, g2, C, dbias, 0);
 }
 
+// Reduction + finalize of that backward alone (the recomputing stem applies it inside its weight-gradient kernel,
+// conv_stem_fused.hip): dgamma, dbeta and *bcoef_out = [3][C] (gamma * invstd, mean dz, mean dz * xhat) inside `scratch`.
+int ecg_pool_bn_bwd_reduce(int dtype, const void* dp, const void* pooled, const float* coef, const float* gamma, float* dgamma,
+                           float* dbeta, int N, int H, int W, int C, float* scratch, const float** bcoef_out,
+                           hipStream_t stream) {
+  if (dtype != ECGMM_BF16) ECG_FAIL(ECGMM_ERR_DTYPE, "pool_bn_bwd_reduce: bf16 only");
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "pool_bn_bwd_reduce: C=%d unsupported", C);
+  using T = bf16_t;
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr size_t lds2 = (size_t)BWD_THREADS * (2 * VEC + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pool_bwd_reduce_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    attr_set = true;
+  }
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const int rows = bn_bwd_rows(dtype, (long)N * H * W, C);
+  const long MP = (long)N * OH * OW, M = (long)N * H * W;
+  float* partial = scratch;
+  float* bcoef = scratch + (size_t)(rows + ECG_TAIL_ROWS) * 2 * C;
+  const int rpi = BWD_THREADS / (C / VEC);
+  int g1 = ew_grid(MP, rpi * 8);
+  g1 = g1 > rows ? rows : g1;
+  hipLaunchKernelGGL(pool_bwd_reduce_kernel<T>, dim3(g1), dim3(BWD_THREADS), lds2, stream, (const T*)dp, (const T*)pooled, coef,
+                     partial, MP, C);
+  ECG_CHECK_LAUNCH("pool_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, (const float*)partial, g1, C,
+                     (double)M, gamma, coef, dgamma, dbeta, bcoef, 1);
+  ECG_CHECK_LAUNCH("bn_bwd_finalize");
+  *bcoef_out = bcoef;
+  return 0;
+}
+
 // ECGMM_STEM_FUSE=0: the plans fall back to max-pool backward + full BatchNorm backward as separate passes (A/B switch)
 bool ecg_stem_fuse_on() {
   static const bool on = [] { const char* e = getenv("ECGMM_STEM_FUSE"); return !(e && e[0] == '0'); }();

@@ -46,7 +46,22 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
 size_t ecg_stem_wgrad_workspace(int N, int Cin, int H, int W, int R);
 int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int accumulate, void* workspace,
                    size_t workspace_bytes, int N, int Cin, int H, int W, int R, hipStream_t stream);
+int ecg_stem_stats_only_rows(int N, int Cin, int H, int W, int R);
+int ecg_stem_stats_only(int dtype, const float* x, const void* wpk, const float* bias, float* stats, int N, int Cin, int H,
+                        int W, int R, hipStream_t stream);
+int ecg_stem_wgrad_reduce(const float* slab, float* grad, int rows, int NG, int accumulate, hipStream_t stream);
+// conv_stem_fused.hip: the 2-D stem by recompute (bf16, R = 7, Cin <= 3): conv -> bn -> relu -> max-pool, no full-resolution tensor
+bool ecg_stem_fused_ok(int dtype, int Cin, int R);
+int ecg_stem_pool_fwd(const float* x, const void* wpk, const float* coef, void* pooled, unsigned char* idx, int N, int Cin,
+                      int H, int W, hipStream_t stream);
+size_t ecg_stem_pool_bwd_workspace(int N, int Cin, int H, int W);
+int ecg_stem_pool_bwd(const float* x, const void* wpk, const float* coef, const float* gamma, const void* dp, const void* pooled,
+                      const unsigned char* idx, float* dgamma, float* dbeta, float* dw, void* ws, size_t ws_bytes, int N,
+                      int Cin, int H, int W, hipStream_t stream);
 // elementwise.hip
+int ecg_pool_bn_bwd_reduce(int dtype, const void* dp, const void* pooled, const float* coef, const float* gamma, float* dgamma,
+                           float* dbeta, int N, int H, int W, int C, float* scratch, const float** bcoef_out,
+                           hipStream_t stream);
 int ecg_bn_rows(int dtype, long M, int C);
 int ecg_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                     float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef, hipStream_t stream);

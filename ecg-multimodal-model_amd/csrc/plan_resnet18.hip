@@ -18,6 +18,11 @@
 #include "side_stream.h"
 
 namespace {
+int g_stem_recompute = -1;  // the 2-D stem by recompute (conv_stem_fused.hip): -1 = read ECGMM_STEM_RECOMPUTE (default on)
+bool stem_recompute(int dtype) {
+  if (g_stem_recompute < 0) { const char* e = getenv("ECGMM_STEM_RECOMPUTE"); g_stem_recompute = !(e && e[0] == '0'); }
+  return g_stem_recompute != 0 && ecg_stem_fused_ok(dtype, 3, 7);
+}
 long g_fuse_min_m = -1;  // pixel-count threshold of the fused BatchNorm-backward reductions (-1: read ECGMM_BN_FUSE_MIN_M)
 
 struct BlockCfg {
@@ -96,11 +101,13 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
   const size_t es = dtype_size(r.d.dtype);
   const int N = r.d.N;
   w.wstem = a.take_bytes(ecg_stem_packed_elems(3, 7) * es);
-  w.y0 = a.take_bytes((size_t)N * r.H1 * r.W1 * 64 * es);
+  // (the recomputing stem never materialises the conv output)
+  w.y0 = stem_recompute(r.d.dtype) ? nullptr : a.take_bytes((size_t)N * r.H1 * r.W1 * 64 * es);
   w.coef0 = a.take<float>(4 * 64);
   w.p0 = a.take_bytes((size_t)N * r.H2 * r.W2 * 64 * es);
   w.idx0 = a.take<unsigned char>((size_t)N * r.H2 * r.W2 * 64);
-  size_t max_rows_c = (size_t)ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7) * 2 * 64;
+  size_t max_rows_c = (size_t)(stem_recompute(r.d.dtype) ? ecg_stem_stats_only_rows(N, 3, r.d.H, r.d.W, 7)
+                                                          : ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7)) * 2 * 64;
   max_rows_c += (size_t)ECG_TAIL_ROWS * 2 * 64;
   size_t max_rows_d = 64;
   for (int i = 0; i < 8; ++i) {
@@ -171,7 +178,8 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   }
   w.da = a.take_bytes(r.max_act * es);
   w.dtmp = a.take_bytes(r.max_act * es);
-  size_t big = (size_t)N * r.H1 * r.W1 * 64;
+  const bool recompute = stem_recompute(r.d.dtype);
+  size_t big = recompute ? 0 : (size_t)N * r.H1 * r.W1 * 64;   // (recomputing stem: neither dz0 nor dy0 exist)
   w.big0 = a.take_bytes(big * es);
   w.big1 = a.take_bytes(big * es);
   w.dpooled = a.take<float>((size_t)N * 512);
@@ -195,7 +203,7 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
   w.red2 = a.take<float>((size_t)256 * 2 * 512);
   w.wg_ws = a.take_bytes(wg);
   w.wg_bytes = wg;
-  w.stem_bytes = ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);
+  w.stem_bytes = recompute ? ecg_stem_pool_bwd_workspace(N, 3, r.d.H, r.d.W) : ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);
   w.stem_ws = a.take_bytes(w.stem_bytes);
   w.lin_bytes = ecg_linear_bwd_scratch(N, 512, r.d.out_dim);
   w.lin_ws = a.take_bytes(w.lin_bytes);
@@ -312,10 +320,19 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   }
   // ---- stem
   ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, 3, 7, s));
-  ECG_TRY(ecg_stem_fwd(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
-  ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
-                  buffers, 0, w.coef0, s));
-  ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
+  if (stem_recompute(dt)) {
+    // pass 1: statistics only; pass 2: conv recomputed -> bn -> relu -> max-pool.  The 64 x H1 x W1 conv output (411 MB at
+    // batch 256) is never written: 154 + 154 MB read, 154 MB written instead of 154 + 411 + 411 read/written + 154
+    if (stats_rows) ECG_TRY(ecg_stem_stats_only(dt, image, w.wstem, nullptr, w.stats, N, 3, r.d.H, r.d.W, 7, s));
+    ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_only_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
+                    buffers, 0, w.coef0, s));
+    ECG_TRY(ecg_stem_pool_fwd(image, w.wstem, w.coef0, w.p0, w.idx0, N, 3, r.d.H, r.d.W, s));
+  } else {
+    ECG_TRY(ecg_stem_fwd(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
+    ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
+                    buffers, 0, w.coef0, s));
+    ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
+  }
 
   const void* cur = w.p0;
   for (int i = 0; i < 8; ++i) {
@@ -497,6 +514,14 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       }
     } else if (st == 9) {
       const void* dp0 = q.X[8 & 1];
+      if (stem_recompute(dt)) {
+        // BatchNorm-backward reduction over the pooled tensors, then ONE kernel: conv recomputed per tile, max-pool backward
+        // gathered, BatchNorm backward applied, weight-gradient products taken -- neither y0 nor dy0 exist.  On the
+        // caller's stream like the stem wgrad it replaces (see below); own workspace q.stem_ws.
+        ECG_TRY(ecg_stem_pool_bwd(image, w.wstem, w.coef0, P(params, 1), dp0, w.p0, w.idx0, G(grads, 1), G(grads, 2),
+                                  G(grads, 0), q.stem_ws, q.stem_bytes, N, 3, r.d.H, r.d.W, s));
+        continue;
+      }
       if (ecg_stem_fuse_on()) {
         ECG_TRY(ecg_pool_bn_bwd(dt, dp0, w.p0, w.idx0, w.y0, w.coef0, P(params, 1), G(grads, 1), G(grads, 2), q.big1,
                                 nullptr, N, r.H1, r.W1, 64, q.bn_scratch, s));
@@ -520,6 +545,14 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
     (void)hipEventRecord(e, g_side.s);
     (void)hipStreamWaitEvent(s, e, 0);
   }
+  return 0;
+}
+
+// The image encoder's stem by recompute (conv_stem_fused.hip): 1 = on (default for bf16), 0 = the two-pass route with the
+// full-resolution conv output in memory.  Start-up value: ECGMM_STEM_RECOMPUTE.  Changes the workspace layouts: set it
+// between steps, never between a forward and its backward.
+extern "C" int ecgmm_stem_recompute(int on) {
+  g_stem_recompute = on != 0;
   return 0;
 }
 

@@ -79,6 +79,11 @@ SIGNATURES = {
     "ecgmm_stem_stats_rows": (i32, [i32, i32, i32, i32, i32]),
     "ecgmm_stem_pack": (i32, [i32, vp, vp, i32, i32, vp]),
     "ecgmm_stem_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ecgmm_stem_stats_only_rows": (i32, [i32, i32, i32, i32, i32]),
+    "ecgmm_stem_stats_only": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ecgmm_stem_pool_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ecgmm_stem_pool_bwd_workspace": (sz, [i32, i32, i32, i32]),
+    "ecgmm_stem_pool_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
     "ecgmm_stem_bwd_weight_workspace": (sz, [i32, i32, i32, i32, i32]),
     "ecgmm_stem_bwd_weight": (i32, [i32, vp, vp, vp, i32, vp, sz, i32, i32, i32, i32, i32, vp]),
     "ecgmm_col_stats_rows": (i32, [i32, i64, i32]),
@@ -94,6 +99,7 @@ SIGNATURES = {
     "ecgmm_bnrelu_maxpool": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_maxpool_relu_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_bn_fuse_min_pixels": (i32, [i64]),
+    "ecgmm_stem_recompute": (i32, [i32]),
     "ecgmm_pool_bn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ecgmm_avgpool": (i32, [i32, vp, vp, i32, i32, i32, vp, vp]),
     "ecgmm_bcast_rows": (i32, [i32, vp, vp, i32, i32, i32, f32, vp]),

@@ -186,6 +186,27 @@ size_t ecgmm_stem_bwd_weight_workspace(int N, int Cin, int H, int W, int R);
 int ecgmm_stem_bwd_weight(int dtype, const float* x, const void* dy, float* dw_oihw, int accumulate, void* ws,
                           size_t ws_bytes, int N, int Cin, int H, int W, int R, void* stream);
 
+/* The 2-D stem BY RECOMPUTE (csrc/conv_stem_fused.hip; bf16, 7x7 stride 2, Cin <= 3): conv1 -> bn1 -> relu -> maxpool of
+ * torchvision's resnet18 (the reference's image encoder, multimodal_paper_modal_balance.py:210) without the
+ * full-resolution conv output ever reaching HBM.
+ *   stem_stats_only   image -> BatchNorm partial sums ([rows][2][64], rows = ecgmm_stem_stats_only_rows; finalize with
+ *                     ecgmm_bn_finalize over N*OH*OW values)
+ *   stem_pool_fwd     image -> conv -> bn(coef) -> relu -> MaxPool(3,2,1): pooled [N,PH,PW,64] bf16 + arg-max bytes; the
+ *                     same values as ecgmm_stem_fwd + ecgmm_bnrelu_maxpool
+ *   stem_pool_bwd     gradient w.r.t. pooled -> dgamma, dbeta of bn1 and (dw_oihw non-null) the conv weight gradient: the
+ *                     conv is recomputed per tile, the max-pool backward gathered, the BatchNorm backward applied and the
+ *                     weight-gradient products taken without writing y or dy.  Same results as ecgmm_pool_bn_bwd +
+ *                     ecgmm_stem_bwd_weight up to fp32 summation order. */
+int ecgmm_stem_stats_only_rows(int N, int Cin, int H, int W, int R);
+int ecgmm_stem_stats_only(int dtype, const float* x, const void* packed, const float* bias, float* stats, int N, int Cin,
+                          int H, int W, int R, void* stream);
+int ecgmm_stem_pool_fwd(const float* x, const void* packed, const float* coef, void* pooled, uint8_t* idx, int N, int Cin,
+                        int H, int W, void* stream);
+size_t ecgmm_stem_pool_bwd_workspace(int N, int Cin, int H, int W);
+int ecgmm_stem_pool_bwd(const float* x, const void* packed, const float* coef, const float* gamma, const void* dp,
+                        const void* pooled, const uint8_t* idx, float* dgamma, float* dbeta, float* dw_oihw, void* ws,
+                        size_t ws_bytes, int N, int Cin, int H, int W, void* stream);
+
 /* nn.BatchNorm{1,2}d (train: batch mean / biased var, running update with unbiased var; eval: running
  * stats).  coef = [4][C]: scale, shift, mean, invstd.
  * Partial-sum buffers ([rows][2][C] floats, written by conv_fwd / stem_fwd / col_stats) must be
@@ -240,6 +261,10 @@ int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, con
  * least this many output pixels (default 400000 = the 56x56 stage at batch >= 128; 0 = wherever the halo kernel runs;
  * negative restores the default).  Start-up value: ECGMM_BN_FUSE_MIN_M.  Results differ by fp32 summation order only. */
 int ecgmm_bn_fuse_min_pixels(int64_t m);
+/* ResNet18 plan: run the stem by recompute (ecgmm_stem_stats_only / stem_pool_fwd / stem_pool_bwd; bf16 only): 1 = on
+ * (default), 0 = the two-pass route that keeps the full-resolution conv output.  Start-up value: ECGMM_STEM_RECOMPUTE.
+ * It changes the plan's workspace layout: switch between steps, never between a forward and its backward. */
+int ecgmm_stem_recompute(int on);
 
 /* relu(bn(y)) -> MaxPool(3,2,1) (resnet18.maxpool; ResNet1D_SE.initial[3], PMB:103) and its backward */
 int ecgmm_bnrelu_maxpool(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int N, int H, int W,

@@ -306,6 +306,87 @@ def test_stem_fwd_wgrad(case, dt):
     assert rel_err(dw.cpu(), wr.grad) < (2e-5 if dt == L.F32 else 1e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 64, 64), (1, 3, 50, 83), (3, 3, 37, 100), (2, 2, 40, 40), (5, 1, 33, 47),
+                                  (40, 3, 224, 224)])
+def test_stem_by_recompute_matches_the_two_pass_route(case):
+    """csrc/conv_stem_fused.hip (bf16): conv7x7/2 -> bn -> relu -> maxpool(3,2,1) and its backward WITHOUT the
+    full-resolution conv output, against the route that stores it (ecgmm_stem_fwd + bnrelu_maxpool; pool_bn_bwd +
+    stem_bwd_weight -- themselves held to F.conv2d / torch autograd above): the pooled tensor and the arg-max bytes are
+    bit-identical (same MFMA order per output, same rounding points), dgamma / dbeta too (same reduction kernel), the conv
+    weight gradient up to fp32 summation order.  torchvision resnet18 stem, multimodal_paper_modal_balance.py:210."""
+    N, Cin, H, W = case
+    dt, R = L.BF16, 7
+    lib = L.lib()
+    x, w = dev(fill.hash_tensor((N, Cin, H, W), 31)), dev(fill.hash_tensor((64, Cin, R, 7), 32, 0.3))
+    gam, bet = dev(1 + 0.3 * fill.hash_tensor((64,), 33)), dev(0.2 * fill.hash_tensor((64,), 34))
+    gam[5] = -gam[5]                                     # a negative BatchNorm scale: max of relu(bn(y)), not bn(max y)
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    M = N * OH * OW
+    pk = torch.empty(lib.ecgmm_stem_packed_elems(Cin, R), device=DEV, dtype=torch.bfloat16)
+    L.check(lib.ecgmm_stem_pack(dt, ptr(w), ptr(pk), Cin, R, stream()))
+    # ---- two-pass route
+    rows = lib.ecgmm_stem_stats_rows(N, Cin, H, W, R)
+    stats = torch.zeros(rows + 64, 2, 64, device=DEV)
+    y = torch.empty(M * 64, device=DEV, dtype=torch.bfloat16)
+    L.check(lib.ecgmm_stem_fwd(dt, ptr(x), ptr(pk), None, ptr(y), ptr(stats), N, Cin, H, W, R, stream()))
+    col = stats[:rows].sum(0)
+    coef = torch.empty(4, 64, device=DEV)
+    rm, rv, nbt = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    L.check(lib.ecgmm_bn_finalize(ptr(stats), rows, 64, float(M), ptr(gam), ptr(bet), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5,
+                                  ptr(coef), stream()))
+    p_ref = torch.empty(N * PH * PW * 64, device=DEV, dtype=torch.bfloat16)
+    i_ref = torch.empty(N * PH * PW * 64, device=DEV, dtype=torch.uint8)
+    L.check(lib.ecgmm_bnrelu_maxpool(dt, ptr(y), ptr(coef), ptr(p_ref), ptr(i_ref), N, OH, OW, 64, stream()))
+    # ---- recompute: statistics pass
+    rows2 = lib.ecgmm_stem_stats_only_rows(N, Cin, H, W, R)
+    stats2 = torch.full((rows2 + 64, 2, 64), float("nan"), device=DEV)
+    L.check(lib.ecgmm_stem_stats_only(dt, ptr(x), ptr(pk), None, ptr(stats2), N, Cin, H, W, R, stream()))
+    col2 = stats2[:rows2].sum(0)
+    assert torch.isfinite(col2).all()
+    assert torch.allclose(col2, col, rtol=2e-5, atol=1e-5 * float(col.abs().max()) + 1e-3), float((col2 - col).abs().max())
+    coef2 = torch.empty(4, 64, device=DEV)
+    rm2, rv2, nbt2 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    L.check(lib.ecgmm_bn_finalize(ptr(stats2), rows2, 64, float(M), ptr(gam), ptr(bet), ptr(rm2), ptr(rv2), ptr(nbt2), 0.1,
+                                  1e-5, ptr(coef2), stream()))
+    assert torch.allclose(coef2, coef, rtol=1e-4, atol=1e-5) and torch.allclose(rv2, rv, rtol=1e-4)
+    # ---- recompute: pooled forward (the SAME coefficients, so every bit can be compared)
+    p_new = torch.full((N * PH * PW * 64,), float("nan"), device=DEV, dtype=torch.bfloat16)
+    i_new = torch.full((N * PH * PW * 64,), 77, device=DEV, dtype=torch.uint8)
+    L.check(lib.ecgmm_stem_pool_fwd(ptr(x), ptr(pk), ptr(coef), ptr(p_new), ptr(i_new), N, Cin, H, W, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(p_new.view(torch.int16), p_ref.view(torch.int16)), int((p_new.view(torch.int16) != p_ref.view(torch.int16)).sum())
+    assert torch.equal(i_new, i_ref), int((i_new != i_ref).sum())
+    # ---- backward
+    dp = to_nhwc(bf16_round(fill.hash_tensor((N, 64, PH, PW), 35)), dt)
+    scratch = torch.empty(lib.ecgmm_bn_bwd_scratch(dt, M, 64), device=DEV, dtype=torch.uint8)
+    dy = torch.empty_like(y)
+    dgam, dbet = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    L.check(lib.ecgmm_pool_bn_bwd(dt, ptr(dp), ptr(p_ref), ptr(i_ref), ptr(y), ptr(coef), ptr(gam), ptr(dgam), ptr(dbet),
+                                  ptr(dy), None, N, OH, OW, 64, ptr(scratch), stream()))
+    nb = lib.ecgmm_stem_bwd_weight_workspace(N, Cin, H, W, R)
+    ws = torch.empty(nb, device=DEV, dtype=torch.uint8)
+    dw_ref = torch.zeros_like(w)
+    L.check(lib.ecgmm_stem_bwd_weight(dt, ptr(x), ptr(dy), ptr(dw_ref), 0, ptr(ws), nb, N, Cin, H, W, R, stream()))
+    nb2 = lib.ecgmm_stem_pool_bwd_workspace(N, Cin, H, W)
+    ws2 = torch.empty(nb2, device=DEV, dtype=torch.uint8)
+    dw = torch.full_like(w, float("nan"))
+    dgam2, dbet2 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    L.check(lib.ecgmm_stem_pool_bwd(ptr(x), ptr(pk), ptr(coef), ptr(gam), ptr(dp), ptr(p_ref), ptr(i_ref), ptr(dgam2),
+                                    ptr(dbet2), ptr(dw), ptr(ws2), nb2, N, Cin, H, W, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet)
+    err = rel_err(dw.cpu(), dw_ref.cpu())
+    print("stem weight gradient, recompute vs two-pass: rel err %.2e, bit-identical %s" % (err, torch.equal(dw, dw_ref)))
+    assert err < 1e-5, err
+    # frozen conv weight (dw = NULL): the BatchNorm gradients alone
+    dgam3, dbet3 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    L.check(lib.ecgmm_stem_pool_bwd(ptr(x), ptr(pk), ptr(coef), ptr(gam), ptr(dp), ptr(p_ref), ptr(i_ref), ptr(dgam3),
+                                    ptr(dbet3), None, ptr(ws2), nb2, N, Cin, H, W, stream()))
+    assert torch.equal(dgam3, dgam)
+    assert lib.ecgmm_stem_pool_fwd(ptr(x), ptr(pk), ptr(coef), ptr(p_new), ptr(i_new), N, 4, H, W, stream()) != 0   # Cin > 3
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 @pytest.mark.parametrize("shape", [(3, 64, 9, 11), (2, 128, 1, 77), (5, 256, 4, 4)])
 def test_batchnorm_train_fwd_bwd_with_residual_and_gate(dt, shape):
