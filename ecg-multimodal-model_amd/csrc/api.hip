@@ -129,6 +129,12 @@ int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* d
   if (rc == 0 && e.red_done) *nrows = e.red_rows_n;
   return rc;
 }
+// Partial rows a launch of ecgmm_conv_bwd_data_bnred writes for this geometry (0 = the fused form does not apply): the
+// number an encoder plan uses when ANOTHER call consumes the rows (csrc/plan_resnet18.hip) -- follows ecgmm_conv_halo_cus.
+int ecgmm_conv_bwd_data_bnred_rows(int dtype, const ecgmm_conv_desc* c) {
+  const ConvGeom g = geom_of(c);
+  return ecg_conv_halo_ok(dtype, 1, g) ? ecg_conv_halo_rows(1, g) : 0;
+}
 int ecgmm_conv_bwd_data_with_downsample(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
                                         const void* dy_down, const void* w_down_dgrad, void* dx, void* tmp,
                                         void* stream) {

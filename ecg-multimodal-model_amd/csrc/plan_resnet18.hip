@@ -18,9 +18,13 @@
 #include "side_stream.h"
 
 namespace {
-int g_stem_recompute = -1;  // the 2-D stem by recompute (conv_stem_fused.hip): -1 = read ECGMM_STEM_RECOMPUTE (default on)
+// The 2-D stem by recompute (conv_stem_fused.hip): -1 = read ECGMM_STEM_RECOMPUTE.  DEFAULT OFF: measured in the step
+// (same-call A/B, batch 256, round 3) it removes 1.6 GB of fabric traffic per step and is 0.2 ms SLOWER (7.12 -> 7.32 ms):
+// its kernels are VALU-issue-bound (~2600 instructions per 128-pixel tile for 96 MFMAs), not byte-bound -- stand-alone
+// forward 418 -> 396 us, backward 401 -> 584 us.  Kept as a tested option (memory: -1.2 GB of workspace at batch 256).
+int g_stem_recompute = -1;
 bool stem_recompute(int dtype) {
-  if (g_stem_recompute < 0) { const char* e = getenv("ECGMM_STEM_RECOMPUTE"); g_stem_recompute = !(e && e[0] == '0'); }
+  if (g_stem_recompute < 0) { const char* e = getenv("ECGMM_STEM_RECOMPUTE"); g_stem_recompute = (e && e[0] == '1'); }
   return g_stem_recompute != 0 && ecg_stem_fused_ok(dtype, 3, 7);
 }
 long g_fuse_min_m = -1;  // pixel-count threshold of the fused BatchNorm-backward reductions (-1: read ECGMM_BN_FUSE_MIN_M)
@@ -548,8 +552,8 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   return 0;
 }
 
-// The image encoder's stem by recompute (conv_stem_fused.hip): 1 = on (default for bf16), 0 = the two-pass route with the
-// full-resolution conv output in memory.  Start-up value: ECGMM_STEM_RECOMPUTE.  Changes the workspace layouts: set it
+// The image encoder's stem by recompute (conv_stem_fused.hip): 1 = on (bf16 only), 0 = the two-pass route with the
+// full-resolution conv output in memory (default: faster, see above).  Start-up value: ECGMM_STEM_RECOMPUTE.  Changes the workspace layouts: set it
 // between steps, never between a forward and its backward.
 extern "C" int ecgmm_stem_recompute(int on) {
   g_stem_recompute = on != 0;

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ecgmm_bn_bwd": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "ecgmm_conv_bwd_data_with_downsample": (i32, [i32, P(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "ecgmm_conv_bwd_data_bnred": (i32, [i32, P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, P(i32), vp]),
+    "ecgmm_conv_bwd_data_bnred_rows": (i32, [i32, P(ConvDesc)]),
     "ecgmm_bn_bwd_from_rows": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, vp]),
     "ecgmm_bnrelu_maxpool": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_maxpool_relu_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -244,6 +244,9 @@ int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* 
 int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad,
                               const void* addend, void* dx, const void* bn_y, const void* bn_mask, const float* bn_coef,
                               float* rows, int* nrows, void* stream);
+/* rows a launch of ecgmm_conv_bwd_data_bnred writes for this geometry under the current settings (0: the fused form does
+ * not apply and *nrows will be 0) -- for callers whose consumer runs in another call; follows ecgmm_conv_halo_cus */
+int ecgmm_conv_bwd_data_bnred_rows(int dtype, const ecgmm_conv_desc* c);
 /* Input gradient of a ResNet stage-entry block's two stride-2 branches in one launch (torchvision BasicBlock with
  * downsample; BasicBlock1D, multimodal_paper_modal_balance.py:71-93):  dx = dgrad(conv c, dy) + dgrad(1x1 stride-2 pad-0
  * conv of the same input, dy_down).  The 1x1 branch is one more tap of the stride-2 kernel's parity class (0,0); no
@@ -261,8 +264,9 @@ int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, con
  * least this many output pixels (default 400000 = the 56x56 stage at batch >= 128; 0 = wherever the halo kernel runs;
  * negative restores the default).  Start-up value: ECGMM_BN_FUSE_MIN_M.  Results differ by fp32 summation order only. */
 int ecgmm_bn_fuse_min_pixels(int64_t m);
-/* ResNet18 plan: run the stem by recompute (ecgmm_stem_stats_only / stem_pool_fwd / stem_pool_bwd; bf16 only): 1 = on
- * (default), 0 = the two-pass route that keeps the full-resolution conv output.  Start-up value: ECGMM_STEM_RECOMPUTE.
+/* ResNet18 plan: run the stem by recompute (ecgmm_stem_stats_only / stem_pool_fwd / stem_pool_bwd; bf16 only): 1 = on,
+ * 0 = the two-pass route that keeps the full-resolution conv output (default: 0.2 ms per step faster at batch 256 although
+ * it moves 1.6 GB more -- the recomputing kernels are instruction-bound).  Start-up value: ECGMM_STEM_RECOMPUTE.
  * It changes the plan's workspace layout: switch between steps, never between a forward and its backward. */
 int ecgmm_stem_recompute(int on);
 

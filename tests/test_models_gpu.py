@@ -275,12 +275,15 @@ def _dev_vs_autocast(make_ref, make_net, x, loss_of, keys):
 @pytest.fixture(params=["default", "everywhere"])
 def conv_kernel_choice(request):
     """default: the plans pick kernels/fusions by their size rules (small test shapes -> general kernels, separate passes);
-    everywhere: the halo conv kernel, the ring wgrad kernel and the fused BatchNorm-backward reductions wherever applicable"""
+    everywhere: the halo conv kernel, the ring wgrad kernel and the fused BatchNorm-backward reductions wherever applicable,
+    and the stem by recompute (csrc/conv_stem_fused.hip: an option, off by default)"""
     from ecgmm.hip import lib as L
     if request.param == "everywhere":
         L.lib().ecgmm_conv_halo_enable(2); L.lib().ecgmm_conv_wgrad_ring_enable(2); L.lib().ecgmm_bn_fuse_min_pixels(0)
+        L.lib().ecgmm_stem_recompute(1)
     yield request.param
     L.lib().ecgmm_conv_halo_enable(1); L.lib().ecgmm_conv_wgrad_ring_enable(1); L.lib().ecgmm_bn_fuse_min_pixels(-1)
+    L.lib().ecgmm_stem_recompute(0)
 
 
 @pytest.mark.parametrize("shape", [(4, 3, 64, 64), (8, 3, 128, 96)])

@@ -246,6 +246,63 @@ def test_dgrad_with_fused_batchnorm_backward_reduction(case, sep_mask):
     assert rel_err(a[0], yr.grad) < 2e-2 and rel_err(a[1], gr.grad) < 1e-2 and rel_err(a[2], br.grad) < 1e-2
 
 
+@pytest.mark.parametrize("cap", [0, 64, 7])
+def test_fused_reduction_row_count_follows_the_halo_cu_cap(cap):
+    """with the persistent conv kernel capped to fewer CUs (ECGMM_HALO_CUS / ecgmm_conv_halo_cus) a launch writes
+    fewer partial rows of the fused BatchNorm-backward reduction.  The count a plan uses when the rows are consumed by a
+    LATER call (csrc/plan_resnet18.hip: bn2's reduction rides on the next block's dgrad) is
+    ecgmm_conv_bwd_data_bnred_rows: it must equal what the launch wrote, rows past it stay untouched, and the finished
+    backward must not depend on the cap beyond fp32 summation order."""
+    N, H, W, Cin, Cout = 32, 16, 16, 64, 64        # 32 pixel tiles: more tiles than 7 workgroups, fewer than 64
+    lib = L.lib()
+    dt = L.BF16
+    M = N * H * W
+    d = conv_desc(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    y = bf16_round(fill.hash_tensor((N, Cin, H, W), 61, 2.0) + 0.3)
+    w = bf16_round(fill.hash_tensor((Cout, Cin, 3, 3), 63, 0.05))
+    dy = bf16_round(fill.hash_tensor((N, Cout, H, W), 64))
+    gam, bet = dev(1 + 0.2 * fill.hash_tensor((Cin,), 65)), dev(0.1 * fill.hash_tensor((Cin,), 66))
+    yg, dyg = to_nhwc(y, dt), to_nhwc(dy, dt)
+    _, wd = pack_weight(w, dt)
+    rows = lib.ecgmm_col_stats_rows(dt, M, Cin)
+    part = torch.zeros(rows + 64, 2, Cin, device=DEV)
+    L.check(lib.ecgmm_col_stats(dt, ptr(yg), M, Cin, ptr(part), stream()))
+    coef = torch.empty(4, Cin, device=DEV)
+    L.check(lib.ecgmm_bn_finalize(ptr(part), rows, Cin, float(M), ptr(gam), ptr(bet), None, None, None, 0.1, 1e-5, ptr(coef), stream()))
+    scratch = torch.empty(lib.ecgmm_bn_bwd_scratch(dt, M, Cin), device=DEV, dtype=torch.uint8)
+
+    def run():
+        dx = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+        dyo = torch.empty(M * Cin, device=DEV, dtype=torch.bfloat16)
+        dgam, dbet = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+        rows_buf = torch.full((256, 2, Cin), float("nan"), device=DEV)
+        n = C.c_int(0)
+        want = lib.ecgmm_conv_bwd_data_bnred_rows(dt, C.byref(d))
+        L.check(lib.ecgmm_conv_bwd_data_bnred(dt, C.byref(d), ptr(dyg), ptr(wd), None, ptr(dx), ptr(yg), ptr(yg), ptr(coef),
+                                              ptr(rows_buf), C.byref(n), stream()))
+        torch.cuda.synchronize()
+        assert n.value == want >= 1, (n.value, want)
+        assert torch.isfinite(rows_buf[:n.value]).all() and torch.isnan(rows_buf[n.value:]).all()
+        L.check(lib.ecgmm_bn_bwd_from_rows(dt, ptr(dx), ptr(yg), ptr(yg), ptr(coef), ptr(gam), ptr(dgam), ptr(dbet), ptr(dyo),
+                                           ptr(rows_buf), want, M, Cin, ptr(scratch), stream()))
+        torch.cuda.synchronize()
+        return n.value, dx.clone(), dyo.float().cpu(), dgam.cpu(), dbet.cpu()
+
+    try:
+        lib.ecgmm_conv_halo_enable(2)
+        lib.ecgmm_conv_halo_cus(0)
+        full = run()
+        lib.ecgmm_conv_halo_cus(cap)
+        capped = run()
+    finally:
+        lib.ecgmm_conv_halo_cus(0)
+        lib.ecgmm_conv_halo_enable(1)
+    assert capped[0] == (min(cap, 32) if cap else full[0])
+    assert torch.equal(capped[1], full[1])                                  # the gradient itself: pure scheduling
+    for u, v in zip(capped[2:], full[2:]):
+        assert rel_err(u, v) < 1e-5
+
+
 def test_conv_rejects_bad_shapes():
     lib = L.lib()
     d = conv_desc(1, 8, 8, 6, 64, 3, 3, 1, 1, 1)   # Cin not a multiple of the 16-byte vector
