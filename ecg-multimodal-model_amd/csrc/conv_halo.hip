@@ -29,7 +29,6 @@
 namespace {
 
 constexpr int HBM_ = 256;        // pixels per workgroup
-constexpr int HTHREADS = 512;
 constexpr unsigned H_OOB = 0x80000000u;  // stays out of range after a channel-slice offset is added (tensors < 2 GiB)
 
 struct HaloParams {
@@ -87,29 +86,43 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
-template <int BN> struct HaloCfg {
+// NW = waves per workgroup.  8 (4 pixel quarters x 2 channel halves, 2 waves per SIMD, ONE workgroup per CU, two halo
+// buffers, 4-slot weight ring) is the kernel described above.  NW = 4 (round 3; BN = 64 only): 4 pixel quarters x all 64
+// channels -- the same 64 x 64 wave tile as the BN = 128 form -- in a workgroup small enough for TWO per CU (one halo buffer,
+// 3-slot weight ring: 76 KB): a 64-channel tile has half the MFMAs per tile of a 128-channel one for the same prologue /
+// epilogue, and 8 waves in lock step cannot overlap the two -- two independent workgroups per CU do (one in its K loop while
+// the other stores / builds its address table / waits for its halo).
+template <int BN, int NW = 8> struct HaloCfg {
+  static_assert(NW == 8 || (NW == 4 && BN == 64), "4-wave workgroups: 64-channel tiles only");
   static constexpr int HCAP = BN == 128 ? 320 : 384;  // halo rows a buffer holds (256 + 2 * (W + 1) must fit)
   static constexpr int HBUF = (HCAP + 8) * 128;       // + one 8-row piece whose first row is the all-zero row
+  static constexpr int NHB = NW == 8 ? 2 : 1;          // halo buffers
   static constexpr int WSTAGE = BN * 128;
-  static constexpr int NWS = 4;
-  static constexpr int WBASE = 2 * HBUF;
+  static constexpr int NWS = NW == 8 ? 4 : 3;          // weight ring slots; fills run NWS - 1 steps ahead
+  static constexpr int WBASE = NHB * HBUF;
   static constexpr int SBASE = WBASE + NWS * WSTAGE;   // fp32 [4 pixel quarters][2][BN] partial-row accumulators
   static constexpr int CBASE = SBASE + 4 * 2 * BN * 4;   // fp32 [3][BN]: scale, shift, mean of the fused BatchNorm backward
   static constexpr int TRASH = CBASE + 3 * BN * 4;       // 256 B nobody reads: destination of the L2-prefetch DMAs
   static constexpr int LDS = TRASH + 256;
-  static constexpr int WPS = BN / 64;                 // weight DMA pieces per wave per step
-  static constexpr int NPW_MAX = HCAP / 64;           // halo DMA pieces per wave per channel slice
+  static constexpr int WPS = BN / (8 * NW);           // weight DMA pieces per wave per step
+  static constexpr int NPW_MAX = HCAP / (8 * NW);     // halo DMA pieces per wave per channel slice
+  static constexpr int WCN = NW / 4;                   // channel groups of waves
+  static constexpr int CPW = BN / WCN;                 // channels per wave
 };
 
 // NCS1: instantiation for ONE channel slice per tile (Cs = 64).  The second halo buffer is then idle during a tile's K
 // loop, so the NEXT tile's halo is fetched there during this tile's K loop (through the same in-loop piece schedule
 // that otherwise fetches the next channel slice) instead of from the epilogue, where only ~0.6 us of work covered its
 // HBM latency: 1.5-2 us of exposed wait per tile, 12 tiles per workgroup on the 56x56 layers.
-template <int BN, int RS, int MODE, bool NCS1 = false>
-__global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
-  using C = HaloCfg<BN>;
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(HaloParams p) {
+  using C = HaloCfg<BN, NW>;
+  static_assert(!(NCS1 && NW == 4), "one halo buffer: the next tile's halo cannot stream in during the K loop");
+  static_assert(NW == 8 || RS % 3 == 0, "3-slot ring: the slot of a step is its tap index mod 3");
+  constexpr int HTHREADS = NW * 64;
+  constexpr int D = C::NWS - 1;   // weight fills run D steps ahead
   constexpr int TP = 4;         // 16-pixel tiles per wave (64 pixels)
-  constexpr int TC = BN / 32;   // 16-channel tiles per wave
+  constexpr int TC = C::CPW / 16;   // 16-channel tiles per wave
 #ifndef HALO_HPS9
 #define HALO_HPS9 1   // (all of a slice's halo pieces in its first step, as the 3-tap filters do: 1-2 % slower on layers 2-4)
 #endif
@@ -119,7 +132,10 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wp = wv & 3, wc = wv >> 2;
+  const int wp = wv & 3, wc = wv >> 2;   // (NW == 4: wc == 0)
+  // weight ring slot of K step g (tap t): 4 slots -> g & 3; 3 slots -> t % 3 (every slice has RS = 3 or 9 steps)
+  auto slot_of = [](int g, int t) -> int { return C::NWS == 4 ? (g & 3) : (t % 3); };
+  auto hbuf_of = [](int q) -> unsigned { return C::NHB == 2 ? (unsigned)(q & 1) * C::HBUF : 0u; };
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x;
   // Workgroups are PERSISTENT, and a workgroup stays on ONE channel tile: workgroup b owns channel tile b % ntn and the
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   auto set_hoff = [&](int m0) {
 #pragma unroll
     for (int kk = 0; kk < C::NPW_MAX; ++kk) {
-      const int row = (kk * 8 + wv) * 8 + lrow8;
+      const int row = (kk * NW + wv) * 8 + lrow8;
       const int pix = m0 - p.HL + row;
       const bool ok = row < p.hrows && pix >= 0 && pix < p.M;
       hoff[kk] = ok ? (unsigned)pix * pixb + lchunkb : H_OOB;
@@ -148,24 +164,24 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   };
   auto set_wrow = [&](unsigned (&wr)[C::WPS], int n0) {
 #pragma unroll
-    for (int i = 0; i < C::WPS; ++i) wr[i] = (unsigned)(n0 + (i * 8 + wv) * 8 + lrow8) * (unsigned)RS * pixb + lchunkb;
+    for (int i = 0; i < C::WPS; ++i) wr[i] = (unsigned)(n0 + (i * NW + wv) * 8 + lrow8) * (unsigned)RS * pixb + lchunkb;
   };
   // halo pieces [k0, k1) of this wave, channel slice `cs`, into buffer `hbuf` (a piece wholly past the halo's last row
   // is all out of range: zero fill into rows nobody reads -- the piece count stays a compile-time constant)
   auto dma_halo = [&](unsigned hbuf, int cs, int k0, int k1) {
 #pragma unroll
     for (int kk = 0; kk < C::NPW_MAX; ++kk)
-      if (kk >= k0 && kk < k1) hdma16(rs_src, smem + hbuf + (kk * 8 + wv) * 1024, hoff[kk], (unsigned)cs * 128u);
+      if (kk >= k0 && kk < k1) hdma16(rs_src, smem + hbuf + (kk * NW + wv) * 1024, hoff[kk], (unsigned)cs * 128u);
   };
   auto dma_w = [&](const unsigned (&wr)[C::WPS], int slot, int cs, int t) {
     const unsigned so = ((unsigned)t * (unsigned)p.Cs + (unsigned)cs * 64u) * 2u;
 #pragma unroll
-    for (int i = 0; i < C::WPS; ++i) hdma16(rs_w, smem + C::WBASE + slot * C::WSTAGE + (i * 8 + wv) * 1024, wr[i], so);
+    for (int i = 0; i < C::WPS; ++i) hdma16(rs_w, smem + C::WBASE + slot * C::WSTAGE + (i * NW + wv) * 1024, wr[i], so);
   };
 
   // ---- fragment addresses
   // weights (A operand): row = channel, conflict-free b128 reads via chunk ^ (row & 7)
-  const unsigned aoff0 = (unsigned)C::WBASE + (unsigned)(wc * (BN / 2) + fr) * 128u + (unsigned)((fq ^ (fr & 7)) << 4);
+  const unsigned aoff0 = (unsigned)C::WBASE + (unsigned)(wc * C::CPW + fr) * 128u + (unsigned)((fq ^ (fr & 7)) << 4);
   // activations (B operand): per (pixel tile b, tap t) the halo-relative LDS byte this lane reads for k-step 0
   // (k-step 1 = the same address ^ 64); a tap outside the image reads the zero row
   // (two 16-bit addresses per register: 4 x RS of them live through the whole K loop)
@@ -256,13 +272,12 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   auto tile_fills = [&](int m0_, bool with_halo) {
     if (with_halo) {
       set_hoff(m0_);
-      dma_halo((unsigned)(qs & 1) * C::HBUF, 0, 0, C::NPW_MAX);
+      dma_halo(hbuf_of(qs), 0, 0, C::NPW_MAX);
     }
-    dma_w(wrow, g0 & 3, 0, 0);
-    dma_w(wrow, (g0 + 1) & 3, 0, 1);
-    dma_w(wrow, (g0 + 2) & 3, 0, 2);
+#pragma unroll
+    for (int t = 0; t < D; ++t) dma_w(wrow, slot_of(g0 + t, t), 0, t);
   };
-  if (tid < 16) *reinterpret_cast<u32x4*>(smem + (tid >> 3) * C::HBUF + C::HCAP * 128 + (tid & 7) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (tid < 8 * C::NHB) *reinterpret_cast<u32x4*>(smem + (tid >> 3) * C::HBUF + C::HCAP * 128 + (tid & 7) * 16) = (u32x4){0u, 0u, 0u, 0u};
   float* const sacc = reinterpret_cast<float*>(smem + C::SBASE);
   for (int i = tid; i < 4 * 2 * BN; i += HTHREADS) sacc[i] = 0.f;
   float* const scoef = reinterpret_cast<float*>(smem + C::CBASE);
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
                                     MODE == 1 && p.red_mask != p.red_y ? (const bf16_t*)p.red_mask : nullptr};
   auto prefetch_epilogue_operands = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const size_t e = (size_t)(m0 + wp * 64 + lane) * p.Cd + n0 + wc * (BN / 2);
+    const size_t e = (size_t)(m0 + wp * 64 + lane) * p.Cd + n0 + wc * C::CPW;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const bf16_t* g = pf_base[k] ? pf_base[k] + e : (const bf16_t*)p.wpk;
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
   // and hipcc's LDS-read bookkeeping stays exact.  LAST = the tile's last slice: no fills past the tile's end.
   auto slice = [&](int cs, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    const unsigned hb = (unsigned)(qs & 1) * C::HBUF, hbn = (unsigned)((qs + 1) & 1) * C::HBUF;
+    const unsigned hb = hbuf_of(qs), hbn = hbuf_of(qs + 1);
     // keep the fragment addresses opaque per slice: otherwise their loop-invariant variants (^ 64, + buffer base) are
     // hoisted out of the loop and the kernel spills
 #pragma unroll
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
     for (int t = 0; t < RS; ++t) {
       const int s = g0 + t;
       // (a) k-step 1 of this step into the second register set
-      ld_a(fa1, s & 3, 64u);
+      ld_a(fa1, slot_of(s, t), 64u);
 #pragma unroll
       for (int b = 0; b < TP; ++b) fb1[b] = ld_b((bad(b, t) ^ 64u) + hb);
       // (b) fills THREE steps ahead: weights of step s + 3 go into the slot step s - 1 read (every wave is past that step's
@@ -314,12 +329,12 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       const auto n_halo = [](int tt, bool last) { return (!(last && !NCS1) && tt < RS - 1 && tt * HPS < C::NPW_MAX)
                                                       ? ((tt + 1) * HPS < C::NPW_MAX ? HPS : C::NPW_MAX - tt * HPS) : 0; };
       const auto n_fill = [&](int tt, bool last) {
-        return ((last && tt + 3 >= RS) ? 0 : C::WPS) + n_halo(tt, last) + ((last && tt == 0) ? 3 : 0);
+        return ((last && tt + D >= RS) ? 0 : C::WPS) + n_halo(tt, last) + ((last && tt == 0) ? 3 : 0);
       };
-      const bool wrap = t + 3 >= RS;
+      const bool wrap = t + D >= RS;
       if (LAST && t == 0) prefetch_epilogue_operands();   // 3 DMAs, counted in n_fill
 #if !(defined(HALO_ABL) && HALO_ABL == 3)   // diagnostic 3: no fills inside the K loop
-      if (!(LAST && wrap)) dma_w(wrow, (s + 3) & 3, cs + (wrap ? 1 : 0), (t + 3) % RS);
+      if (!(LAST && wrap)) dma_w(wrow, slot_of(s + D, (t + D) % RS), cs + (wrap ? 1 : 0), (t + D) % RS);
       if (n_halo(t, LAST) > 0) dma_halo(hbn, NCS1 ? 0 : cs + 1, t * HPS, (t + 1) * HPS);   // (NCS1: the next TILE's halo, hoff set at the tile's start)
 #endif
       // (c) k-step 0
@@ -328,8 +343,9 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       // may still be in flight are the previous step's and this step's fills.  (The step before a slice's first one is a
       // non-final slice's last step, or the tile prologue, whose fills were all waited for: a larger count is then moot.)
       // The LDS reads of (a) are back too, so the slots they read may be refilled by the next step.
-      const int outstanding = (t == 0 ? n_fill(RS - 1, false) : n_fill(t - 1, LAST)) + n_fill(t, LAST);
-      static_assert(2 * (C::WPS + C::NPW_MAX) <= 16, "wait_vmcnt table");
+      // (fills D steps ahead: the ones issued in the last D - 1 steps may still be in flight)
+      const int outstanding = (D == 3 ? (t == 0 ? n_fill(RS - 1, false) : n_fill(t - 1, LAST)) : 0) + n_fill(t, LAST);
+      // (a count past the table falls back to vmcnt(0): stricter, never wrong)
       if (outstanding == 0) wait_vmcnt<0>();
       else if (outstanding == 1) wait_vmcnt<1>();
       else if (outstanding == 2) wait_vmcnt<2>();
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       // (e) k-step 0 of the next step (none after the tile's last step)
       if (!(LAST && t == RS - 1)) {
         const int t1 = (t + 1) % RS;
-        ld_a(fa0, (s + 1) & 3, 0u);
+        ld_a(fa0, slot_of(s + 1, t1), 0u);
         const unsigned hb1 = t + 1 < RS ? hb : hbn;
 #pragma unroll
         for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, t1) + hb1);
@@ -385,9 +401,9 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
     first_tile = false;
     wait_lds();
     __builtin_amdgcn_s_barrier();
-    ld_a(fa0, g0 & 3, 0u);
+    ld_a(fa0, slot_of(g0, 0), 0u);
     {
-      const unsigned hb = (unsigned)(qs & 1) * C::HBUF;
+      const unsigned hb = hbuf_of(qs);
 #pragma unroll
       for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, 0) + hb);
     }
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
       const bf16_t* __restrict__ red_y = MODE == 1 ? (const bf16_t*)p.red_y : nullptr;
       const bf16_t* __restrict__ red_m = MODE == 1 ? (const bf16_t*)p.red_mask : nullptr;
       const bool red = red_y != nullptr, red_sep = red && red_m != red_y;
-      const int cw = n0_cur + wc * (BN / 2);                                     // first channel of this wave
+      const int cw = n0_cur + wc * C::CPW;                                       // first channel of this wave
       const int cl = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;                      // + 32 * pair: first of the lane's 8 stored channels
       size_t prow[TP];
 #pragma unroll
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
           const int a = 2 * ap;
           f32x4 c_sc[2], c_sh[2], c_mu[2];
           if (MODE == 1 && red) {   // coefficients of the lane's 8 stored channels (staged in LDS at kernel start)
-            const float* cf = scoef + wc * (BN / 2) + ap * 32 + cl;
+            const float* cf = scoef + wc * C::CPW + ap * 32 + cl;
             c_sc[0] = *reinterpret_cast<const f32x4*>(cf); c_sc[1] = *reinterpret_cast<const f32x4*>(cf + 4);
             c_sh[0] = *reinterpret_cast<const f32x4*>(cf + BN); c_sh[1] = *reinterpret_cast<const f32x4*>(cf + BN + 4);
             c_mu[0] = *reinterpret_cast<const f32x4*>(cf + 2 * BN); c_mu[1] = *reinterpret_cast<const f32x4*>(cf + 2 * BN + 4);
@@ -592,7 +608,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
         // per-channel partial sums of this wave's 64 pixels: 16-lane DPP reduction, then either a row of the per-64-pixel
         // layout (what conv_igemm writes: forward only), or -- wg_rows -- added to this wave's LDS accumulators (only this
         // wave's fr == 0 lanes touch its [pixel quarter][channel] slots: plain read-modify-write, fixed order, reproducible)
-        float* lrow = sacc + wp * 2 * BN + wc * (BN / 2);
+        float* lrow = sacc + wp * 2 * BN + wc * C::CPW;
         if (MODE == 0) {
           float* srow = p.stats + (size_t)(mt_cur * 4 + wp) * 2 * p.Cd + cw + fq * 4;
 #pragma unroll
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(HTHREADS) void conv_halo_kernel(HaloParams p) {
 // tiles.  The ONE place this is computed: the launch and ecg_conv_halo_rows() (whose caller sizes the read of a row
 // buffer another launch fills) must agree for every setting of the cap.
 int g_halo_cu_cap = -1;  // -1: read ECGMM_HALO_CUS at first use; <= 0 after that: no cap
-int halo_gk(int ntn, int ntm) {
+int halo_gk(int ntn, int ntm, int wg_per_cu = 1) {
   static int ncu[16] = {0};
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -671,19 +687,20 @@ int halo_gk(int ntn, int ntm) {
   }
   if (g_halo_cu_cap < 0) { const char* e = getenv("ECGMM_HALO_CUS"); g_halo_cu_cap = e ? atoi(e) : 0; if (g_halo_cu_cap < 0) g_halo_cu_cap = 0; }
   if (g_halo_cu_cap > 0 && cus > g_halo_cu_cap) cus = g_halo_cu_cap;
-  int Gk = cus / (ntn < 1 ? 1 : ntn);
+  int Gk = cus * wg_per_cu / (ntn < 1 ? 1 : ntn);
   if (Gk > ntm) Gk = ntm;
+  if (Gk > 512) Gk = 512;   // (partial-row buffers hold 512 rows: ECGMM_BN_RED_ROWS)
   return Gk < 1 ? 1 : Gk;
 }
 
-template <int BN, int RS, int MODE, bool NCS1 = false>
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8>
 int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
-  using C = HaloCfg<BN>;
+  using C = HaloCfg<BN, NW>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS) != hipSuccess)
       ECG_FAIL(ECGMM_ERR_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", C::LDS);
     attr_set[dev] = true;
@@ -692,13 +709,22 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   q.ntm = p.M / HBM_;
   q.ntn = p.Cd / BN;
   // persistent: one workgroup per CU; Gk workgroups per channel tile (each walks pixel tiles k, k + Gk, ...)
-  const int Gk = halo_gk(q.ntn, q.ntm);
+  // (4-wave workgroups: two per CU)
+  const int Gk = halo_gk(q.ntn, q.ntm, NW == 4 ? 2 : 1);
   *rows_out = Gk;
-  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1>), dim3(Gk * q.ntn), dim3(HTHREADS), C::LDS, stream, q);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
   return 0;
 }
 
+// 64 -> 64 channel 3x3 layers on 4-wave workgroups, two per CU (-1: read ECGMM_HALO_W4).  DEFAULT OFF.  Measured (round 3,
+// batch 256): stand-alone forward 94.5 -> 90.5 us, input gradient 94.7 -> 82.5 us (same-call A/B, tools/conv_bench.py --w4),
+// but the whole step 6.93 -> 7.28 ms: 512 half-size workgroups that CAN share a CU with other streams' waves lose more to the
+// concurrent weight-gradient / signal-encoder kernels than the overlap of their own phases gains.  The instantiation with the
+// fused BatchNorm-backward reduction (MODE 1) is never dispatched on 4 waves: it needs 432 B of scratch per lane, and with
+// compiler-inserted scratch traffic inside the counted-vmcnt K loop its partial rows were NOT reproducible run to run once
+// other streams shared the GPU (tools/det_check_mm.py; every scratch-free instantiation is bit-reproducible).
+int g_halo_w4 = -1;
 int g_halo_enabled = -1;  // read once from ECGMM_CONV_HALO: 0 = off, 1 = where it is the faster kernel (default), 2 = wherever applicable
 
 }  // namespace
@@ -706,6 +732,11 @@ int g_halo_enabled = -1;  // read once from ECGMM_CONV_HALO: 0 = off, 1 = where 
 // Runtime switch (A/B against conv_igemm from one process: tools/conv_bench.py): 0 = never take the halo kernel.
 extern "C" int ecgmm_conv_halo_enable(int on) {
   g_halo_enabled = on < 0 ? 0 : on > 2 ? 2 : on;
+  return 0;
+}
+
+extern "C" int ecgmm_conv_halo_w4(int on) {
+  g_halo_w4 = on != 0;
   return 0;
 }
 
@@ -739,10 +770,15 @@ bool ecg_conv_halo_ok(int dtype, int mode, const ConvGeom& g) {
 }
 
 // partial rows a halo launch with ConvEpi.wg_rows writes: one per workgroup of a channel tile
+static bool halo_w4(const ConvGeom& g, int Cs, int Cd) {
+  if (g_halo_w4 < 0) { const char* e = getenv("ECGMM_HALO_W4"); g_halo_w4 = (e && e[0] == '1'); }
+  return g_halo_w4 && g.R == 3 && Cs == 64 && Cd == 64;
+}
+// (rows of the fused BatchNorm-backward reduction: that instantiation always runs one 8-wave workgroup per CU)
 int ecg_conv_halo_rows(int mode, const ConvGeom& g) {
   const int Cd = mode == 0 ? g.Cout : g.Cin;
   const int ntn = Cd > 64 ? Cd / 128 : 1, ntm = g.N * g.H * g.W / HBM_;
-  return halo_gk(ntn, ntm);
+  return halo_gk(ntn, ntm, 1);
 }
 
 int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk, void* dst, const float* bias,
@@ -772,7 +808,10 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
   // push the BN = 128 instantiation over its 256-VGPR budget (396 B of scratch per lane) whether or not a launch uses it --
   // 13 us of a 88 us layer-2 launch (tools/halo_abl.sh, ablation 7)
   static const bool ncs1_on = [] { const char* e = getenv("ECGMM_HALO_NCS1"); return !(e && e[0] == '0'); }();
-  if (g.R == 3 && !wide && p.ncs == 1 && ncs1_on) {   // the 64 -> 64 channel 3x3 layers: next tile's halo during the K loop
+  if (halo_w4(g, p.Cs, p.Cd) && !p.red_y) {   // the 64 -> 64 channel 3x3 layers: 4-wave workgroups, two per CU (option)
+    if (mode == 0) rc = launch_halo<64, 9, 0, false, 4>(p, &wg, stream);
+    else rc = launch_halo<64, 9, 2, false, 4>(p, &wg, stream);
+  } else if (g.R == 3 && !wide && p.ncs == 1 && ncs1_on) {   // the same on one 8-wave workgroup per CU: next tile's halo during the K loop
     if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
     else if (p.red_y) rc = launch_halo<64, 9, 1, true>(p, &wg, stream);
     else rc = launch_halo<64, 9, 2, true>(p, &wg, stream);

@@ -1091,7 +1091,7 @@ int ecg_bn_rows(int dtype, long M, int C) {
 // Long partial-row buffers are first folded to ECG_TAIL_ROWS rows written into the buffer's tail
 // (callers size partial buffers for rows + ECG_TAIL_ROWS rows), so the finalize kernels stay short.
 static int fold_rows(const float*& partial, int& rows, int width, hipStream_t stream) {
-  if (rows <= 256) return 0;  // the finalize kernels fold short buffers themselves (16 slices x 16 iterations)
+  if (rows <= 512) return 0;  // the finalize kernels fold short buffers themselves (16 slices x <= 32 iterations)
   float* tail = const_cast<float*>(partial) + (size_t)rows * width;
   int chunk = ceil_div(rows, ECG_TAIL_ROWS);
   int nb = ceil_div(rows, chunk);
@@ -1211,7 +1211,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   return 0;
 }
 
-// finalize + apply of a BatchNorm backward whose reduction rows already exist: `partial` = [rows <= 256][2][C] of
+// finalize + apply of a BatchNorm backward whose reduction rows already exist: `partial` = [rows <= 512][2][C] of
 // (sum g, sum g * (y - mean)) written by the epilogue of the dgrad that produced `dout` (conv_halo.hip, ConvEpi).
 // maskref as in ecg_bn_bwd (null when `dout` was stored already masked).
 int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
@@ -1219,7 +1219,7 @@ int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void
                     int C, float* scratch, hipStream_t stream, const float* gate, const float* addc,
                     int rows_per_sample, float* dbias) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
-  if (rows < 1 || rows > 256) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd_tail: %d partial rows (1..256)", rows);
+  if (rows < 1 || rows > 512) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd_tail: %d partial rows (1..512)", rows);
   const int grid = bn_bwd_rows(dtype, M, C);
   float* bcoef = scratch + (size_t)(grid + ECG_TAIL_ROWS) * 2 * C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, (double)M,

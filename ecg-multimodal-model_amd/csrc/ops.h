@@ -11,7 +11,7 @@ struct ConvEpi {
   const void* red_y;      // raw conv output that BatchNorm normalised (same [pixels][channels] layout as dst), or null
   const void* red_mask;   // null / == red_y: mask = (bn(y) > 0), dst stored unmasked; else mask = (red_mask > 0), dst stored MASKED
   const float* red_coef;  // that BatchNorm's forward coefficients [4][C]
-  float* red_rows;        // [>= 256 rows][2][C]
+  float* red_rows;        // [>= 512 rows][2][C] (one row per workgroup of a channel tile; 64-channel tiles run two workgroups per CU)
   int wg_rows;            // in: 1 = the launch may write ONE partial row per workgroup instead of one per 64 pixels
   // in -- stride-2 dgrad only: fold the input gradient of a 1x1 stride-2 pad-0 convolution of the same input (ResNet
   // downsample branch) into this launch: src2 = that branch's output gradient (same shape as src), wpk2 = its dgrad pack.

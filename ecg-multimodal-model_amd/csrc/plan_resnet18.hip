@@ -203,8 +203,8 @@ void layout_bwd(const R18& r, void* base, BwdWs& w) {
     }
   }
   w.bn_scratch = (float*)a.take_bytes(bn);
-  w.red1 = a.take<float>((size_t)256 * 2 * 512);
-  w.red2 = a.take<float>((size_t)256 * 2 * 512);
+  w.red1 = a.take<float>((size_t)512 * 2 * 512);
+  w.red2 = a.take<float>((size_t)512 * 2 * 512);
   w.wg_ws = a.take_bytes(wg);
   w.wg_bytes = wg;
   w.stem_bytes = recompute ? ecg_stem_pool_bwd_workspace(N, 3, r.d.H, r.d.W) : ecg_stem_wgrad_workspace(N, 3, r.d.H, r.d.W, 7);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ecgmm_head_backward": (i32, [P(HeadDesc), P(vp), P(vp), P(vp), P(vp), vp, P(vp), vp, vp, sz, vp]),
     "ecgmm_conv_halo_enable": (i32, [i32]),
     "ecgmm_conv_halo_cus": (i32, [i32]),
+    "ecgmm_conv_halo_w4": (i32, [i32]),
     "ecgmm_conv_wgrad_ring_enable": (i32, [i32]),
     "ecgmm_side_wgrad": (i32, [i32]),
     "ecgmm_side_defer_join": (i32, [i32]),

@@ -162,6 +162,10 @@ int ecgmm_conv_halo_enable(int on);
 /* Cap on the CUs (one persistent workgroup each) a halo-kernel launch occupies; 0 = all of them (default).  The partial-row
  * counts of its fused BatchNorm reductions follow the cap.  Start-up value: ECGMM_HALO_CUS. */
 int ecgmm_conv_halo_cus(int cus);
+/* 64 -> 64 channel 3x3 convolutions (ResNet18 layer 1) on 4-wave workgroups, two per CU, instead of one 8-wave
+ * workgroup per CU: 0 = off (default: faster stand-alone, slower inside the overlapped step), 1 = on.
+ * Start-up value: ECGMM_HALO_W4. */
+int ecgmm_conv_halo_w4(int on);
 /* Weight gradients of the same stride-1 3x3 / 1x3 bf16 convolutions keep their x operand in an LDS ring of pixel rows
  * (wgrad_ring_kernel, csrc/conv_wgrad.hip) instead of one gathered tile per filter tap: 0 = never, 1 = for the shapes
  * it is faster on (default), 2 = wherever applicable (A/B, tests).  Start-up value: ECGMM_WGRAD_RING=0|1|2. */
@@ -237,7 +241,7 @@ int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* 
  * conv -> BatchNorm -> ReLU chains: torchvision BasicBlock, multimodal_paper_modal_balance.py:210; train.py:80):
  * ecgmm_conv_bwd_data_bnred is ecgmm_conv_bwd_data that also accumulates, in its epilogue, the partial rows
  * (sum g, sum g * (bn_y - mean)) of g = [mask] * dx over the pixels, bn_mask == bn_y (or NULL): mask = (bn(bn_y) > 0)
- * and dx is stored unmasked; otherwise mask = (bn_mask > 0) and dx is stored MASKED.  rows: room for 256 x [2][Cin]
+ * and dx is stored unmasked; otherwise mask = (bn_mask > 0) and dx is stored MASKED.  rows: room for 512 x [2][Cin]
  * floats.  *nrows = rows written, or 0 when this geometry is not served by the fused kernel (dx is then the plain
  * gradient and the caller runs ecgmm_bn_bwd).  ecgmm_bn_bwd_from_rows finishes the backward from such rows
  * (finalize + apply; maskref as in ecgmm_bn_bwd, NULL for an already masked dout). */
