@@ -107,6 +107,19 @@ int ecgmm_bn_act(int dtype, const void* y, const float* coef, const void* res, c
                  int rows_per_sample, int relu, void* out, int64_t M, int C, void* stream) {
   return ecg_bn_act(dtype, y, coef, res, rcoef, gate, rows_per_sample, relu, out, (long)M, C, S_(stream));
 }
+int ecgmm_bn_act_from_rows(int dtype, const void* y, const float* partial, int rows, double count, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float momentum, float eps, float* coef_out, const void* res, const float* rcoef,
+                           const float* gate, int rows_per_sample, int relu, void* out, int64_t M, int C, void* stream) {
+  if (!partial || !coef_out) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act_from_rows: null partial rows / coef");
+  if (!ecg_bn_fold_ok(C, rows)) {   // the separate finalize launch, same results
+    ECG_TRY(ecg_bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
+                            momentum, eps, coef_out, S_(stream)));
+    return ecg_bn_act(dtype, y, coef_out, res, rcoef, gate, rows_per_sample, relu, out, (long)M, C, S_(stream));
+  }
+  EcgBnFold f = {partial, rows, count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps};
+  return ecg_bn_act_fold(dtype, y, coef_out, f, res, rcoef, gate, rows_per_sample, relu, out, (long)M, C, S_(stream));
+}
 size_t ecgmm_bn_bwd_scratch(int dtype, int64_t M, int C) { return ecg_bn_bwd_scratch(dtype, (long)M, C); }
 int ecgmm_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
                  int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma,

@@ -150,6 +150,136 @@ __global__ __launch_bounds__(EW_THREADS) void col_stats_kernel(const T* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize FOLDED INTO THE CONSUMER (round 3).  The finalize kernels above are ~5 us launches that sit between
+// a producer and its consumer on the critical path, ~60 of them per step (+ a dependent-launch boundary each).  Here
+// every workgroup of the CONSUMER folds the same <= 512 partial rows itself, in the same fixed order -- every workgroup
+// arrives at bit-identical coefficients, so the result does not depend on which workgroup handles which rows -- and
+// workgroup 0 publishes them (coef / running statistics / dgamma, dbeta) for the later passes that read them from memory.
+// Channels are handled in groups of G = min(C, 128): thread = (channel of the group, row slice), fp64 sums.
+// ------------------------------------------------------------------------------------------------
+struct BnFin {               // forward: partial rows of (sum y, sum y^2) -> scale, shift, mean, invstd
+  const float* partial;      // [rows][2][C]; null = no fold (coefficients come from memory)
+  int rows;
+  double count;
+  const float* gamma;
+  const float* beta;
+  float* rm;                 // running statistics (nullable)
+  float* rv;
+  long long* nbt;
+  float momentum, eps;
+  float* coef_out;           // [4][C], written by workgroup 0
+};
+struct BnBwdFin {            // backward: partial rows of (sum dz, sum dz * xhat | sum dz * (y - mean)) -> k1, k2, k3
+  const float* partial;      // [rows][2][C]; null = no fold
+  int rows;
+  double count;
+  const float* gamma;        // nullable (1)
+  float* dgamma;             // nullable, written by workgroup 0
+  float* dbeta;
+  int centered;              // rows hold sum dz * (y - mean): scale by invstd
+};
+constexpr int FIN_LDS_DOUBLES = 2 * 1024;   // [2][slices][G] with slices * G == block size (1024 threads)
+
+// sums of the two columns of channel group [g0, g0 + G) over all rows -> (s1, s2) in the first G threads
+template <int THREADS>
+__device__ __forceinline__ void fin_fold_group(const float* __restrict__ partial, int rows, int C, int g0, int G, double* s_red,
+                                               double& s1, double& s2) {
+  const int SL = THREADS / G;
+  const int cl = threadIdx.x % G, slice = threadIdx.x / G;
+  const int c = g0 + cl;
+  s1 = 0.0; s2 = 0.0;
+  int r = slice;
+  for (; r + 3 * SL < rows; r += 4 * SL) {   // four rows per trip: eight independent loads in flight
+    float a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* row = partial + (size_t)(r + SL * u) * 2 * C;
+      a[u] = row[c];
+      b[u] = row[C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s1 += (double)a[u];
+      s2 += (double)b[u];
+    }
+  }
+  for (; r < rows; r += SL) {
+    const float* row = partial + (size_t)r * 2 * C;
+    s1 += (double)row[c];
+    s2 += (double)row[C + c];
+  }
+  s_red[slice * G + cl] = s1;
+  s_red[THREADS + slice * G + cl] = s2;
+  __syncthreads();
+  if (slice == 0) {
+    for (int k = 1; k < SL; ++k) {
+      s1 += s_red[k * G + cl];
+      s2 += s_red[THREADS + k * G + cl];
+    }
+  }
+}
+
+// forward fold: s_coef = [2][C] (scale, shift) in LDS for this workgroup; workgroup 0 writes coef_out / running statistics
+template <int THREADS>
+__device__ __forceinline__ void bn_fin_prologue(const BnFin& f, int C, float* s_coef, double* s_red) {
+  const int G = C < 128 ? C : 128;
+  for (int g0 = 0; g0 < C; g0 += G) {
+    double s1, s2;
+    fin_fold_group<THREADS>(f.partial, f.rows, C, g0, G, s_red, s1, s2);
+    if ((int)threadIdx.x < G) {
+      const int c = g0 + threadIdx.x;
+      const double mean = s1 / f.count;
+      double var = s2 / f.count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+      const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+      const float sc = g * invstd;
+      const float sh = b - (float)mean * sc;
+      s_coef[c] = sc;
+      s_coef[C + c] = sh;
+      if (blockIdx.x == 0) {
+        f.coef_out[c] = sc;
+        f.coef_out[C + c] = sh;
+        f.coef_out[2 * C + c] = (float)mean;
+        f.coef_out[3 * C + c] = invstd;
+        if (f.rm) {
+          const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+          f.rm[c] = (1.f - f.momentum) * f.rm[c] + f.momentum * (float)mean;
+          f.rv[c] = (1.f - f.momentum) * f.rv[c] + f.momentum * (float)unb;
+        }
+      }
+    }
+    __syncthreads();   // s_red is reused by the next group; s_coef complete after the last one
+  }
+  if (f.nbt && blockIdx.x == 0 && threadIdx.x == 0) *f.nbt += 1;
+}
+
+// backward fold: s_bcoef = [3][C] (gamma * invstd, mean dz, mean dz * xhat) in LDS; workgroup 0 writes dgamma / dbeta
+template <int THREADS>
+__device__ __forceinline__ void bn_bwd_fin_prologue(const BnBwdFin& f, const float* __restrict__ coef, int C, float* s_bcoef,
+                                                    double* s_red) {
+  const int G = C < 128 ? C : 128;
+  for (int g0 = 0; g0 < C; g0 += G) {
+    double s1, s2;
+    fin_fold_group<THREADS>(f.partial, f.rows, C, g0, G, s_red, s1, s2);
+    if ((int)threadIdx.x < G) {
+      const int c = g0 + threadIdx.x;
+      const float inv = coef[3 * C + c];
+      if (f.centered) s2 *= (double)inv;
+      s_bcoef[c] = (f.gamma ? f.gamma[c] : 1.f) * inv;
+      s_bcoef[C + c] = (float)(s1 / f.count);
+      s_bcoef[2 * C + c] = (float)(s2 / f.count);
+      if (blockIdx.x == 0) {
+        if (f.dgamma) f.dgamma[c] = (float)s2;
+        if (f.dbeta) f.dbeta[c] = (float)s1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BN apply: out = relu?( (y*scale+shift) * gate[n][c] + residual ), residual optionally affine
 // ------------------------------------------------------------------------------------------------
@@ -162,6 +292,7 @@ struct BnActParams {
   void* out;
   long M;
   int C, rows_per_sample, relu;
+  BnFin fin;               // fin.partial != null: the coefficients are folded from the producer's partial rows here
 };
 
 #ifndef BN_ACT_THREADS
@@ -173,11 +304,19 @@ __global__ __launch_bounds__(BN_ACT_THREADS) void bn_act_kernel(BnActParams p) {
   const int cpr = p.C / VEC, rpi = BN_ACT_THREADS / cpr;
   const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
   const int c0 = chunk * VEC;
+  __shared__ double s_red[FIN_LDS_DOUBLES];
+  __shared__ float s_coef[2 * 512];
+  const float* cf = p.coef;
+  int cfs = p.C;           // stride between the scale and the shift rows
+  if (p.fin.partial) {
+    bn_fin_prologue<BN_ACT_THREADS>(p.fin, p.C, s_coef, s_red);
+    cf = s_coef;
+  }
   float sc[VEC], sh[VEC], rs[VEC], rb[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    sc[j] = p.coef[c0 + j];
-    sh[j] = p.coef[p.C + c0 + j];
+    sc[j] = cf[c0 + j];
+    sh[j] = cf[cfs + c0 + j];
     rs[j] = p.rcoef ? p.rcoef[c0 + j] : 1.f;
     rb[j] = p.rcoef ? p.rcoef[p.C + c0 + j] : 0.f;
   }
@@ -242,6 +381,7 @@ struct BnBwdParams {
   float* partial;        // reduce: [grid][2][C]; apply: nullable [grid][C] partial sum(dy)
   long M;
   int C, rows_per_sample;
+  BnBwdFin fin;          // apply only; fin.partial != null: bcoef is folded from the reduction's partial rows here
 };
 
 // 1024-thread blocks: at most 256 partial rows per launch, which the finalize / bias-sum kernels fold themselves (a
@@ -255,6 +395,13 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
   const int cpr = p.C / VEC, rpi = BWD_THREADS / cpr;
   const int chunk = threadIdx.x % cpr, r0 = threadIdx.x / cpr;
   const int c0 = chunk * VEC;
+  __shared__ double s_red[APPLY ? FIN_LDS_DOUBLES : 1];
+  __shared__ float s_bcoef[APPLY ? 3 * 512 : 1];
+  const float* bc = p.bcoef;
+  if (APPLY && p.fin.partial) {
+    bn_bwd_fin_prologue<BWD_THREADS>(p.fin, p.coef, p.C, s_bcoef, s_red);
+    bc = s_bcoef;
+  }
   float mean[VEC], inv[VEC], k1[VEC], k2[VEC], k3[VEC], a1[VEC], a2[VEC], msc[VEC], msh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -264,9 +411,9 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
     inv[j] = p.coef[3 * p.C + c0 + j];
     a1[j] = a2[j] = 0.f;
     if (APPLY) {
-      k1[j] = p.bcoef[c0 + j];
-      k2[j] = p.bcoef[p.C + c0 + j];
-      k3[j] = p.bcoef[2 * p.C + c0 + j];
+      k1[j] = bc[c0 + j];
+      k2[j] = bc[p.C + c0 + j];
+      k3[j] = bc[2 * p.C + c0 + j];
     }
   }
   const T* dout = (const T*)p.dout;
@@ -1135,10 +1282,44 @@ int ecg_col_stats(int dtype, const void* x, long M, int C, float* partial, int* 
   return 0;
 }
 
+// Finalize folded into the consumer (kernels above): ECGMM_BN_FOLD=0 / ecgmm_bn_fold(0) restores the separate launches.
+static int g_bn_fold = -1;
+extern "C" int ecgmm_bn_fold(int on) {
+  g_bn_fold = on != 0;
+  return 0;
+}
+bool ecg_bn_fold_ok(int C, int rows) {
+  if (g_bn_fold < 0) { const char* e = getenv("ECGMM_BN_FOLD"); g_bn_fold = !(e && e[0] == '0'); }
+  if (!g_bn_fold || rows < 1 || rows > 512 || C > 512) return false;
+  return C >= 128 ? C % 128 == 0 : (C >= 16 && 1024 % C == 0);
+}
+
+// bn_act whose coefficients are folded from the producer's partial rows inside the launch (no bn_finalize launch);
+// `coef` is an OUTPUT here (workgroup 0 writes it for the backward), as are the running statistics.
+int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, const void* res, const float* rcoef,
+                    const float* gate, int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream) {
+  if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act: C=%d unsupported", C);
+  if (!ecg_bn_fold_ok(C, f.rows)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act_fold: C=%d rows=%d not foldable", C, f.rows);
+  BnActParams p;
+  memset(&p, 0, sizeof(p));
+  p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
+  p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
+  p.fin.partial = f.partial; p.fin.rows = f.rows; p.fin.count = f.count; p.fin.gamma = f.gamma; p.fin.beta = f.beta;
+  p.fin.rm = f.rm; p.fin.rv = f.rv; p.fin.nbt = f.nbt; p.fin.momentum = f.momentum; p.fin.eps = f.eps; p.fin.coef_out = coef;
+  int vec = dtype == ECGMM_BF16 ? 8 : 4;
+  int grid = ew_grid(M, (BN_ACT_THREADS / (C / vec)) * 4);
+  if (grid > 256) grid = 256;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(grid), dim3(BN_ACT_THREADS), 0, stream, p),
+             hipLaunchKernelGGL(bn_act_kernel<float>, dim3(grid), dim3(BN_ACT_THREADS), 0, stream, p), "bn_act");
+  ECG_CHECK_LAUNCH("bn_act_fold");
+  return 0;
+}
+
 int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
                int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act: C=%d unsupported", C);
   BnActParams p;
+  memset(&p, 0, sizeof(p));
   p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
@@ -1191,15 +1372,22 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   if (dz_early) p.dz_out = dz_out;
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, false>(p, grid, stream)), (bn_bwd_launch<float, false>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_reduce");
-  {
+  // finalize folded into the apply pass (every workgroup folds the <= 256 rows itself) unless the apply pass reuses the
+  // row buffer for the bias-gradient sums, or there is no apply pass
+  const bool fold = dy && !dbias && ecg_bn_fold_ok(C, grid);
+  if (!fold) {
     const float* pr = partial;
     int rows = grid;  // <= 256: folded by the finalize kernel itself (16 slices x 16 rows)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, pr, rows, C, (double)M,
                        gamma, coef, dgamma, dbeta, bcoef, 0);
+    ECG_CHECK_LAUNCH("bn_bwd_finalize");
   }
-  ECG_CHECK_LAUNCH("bn_bwd_finalize");
   if (!dy) return 0;
   p.bcoef = bcoef; p.dy = dy; p.dz_out = dz_out;
+  if (fold) {
+    p.fin.partial = partial; p.fin.rows = grid; p.fin.count = (double)M; p.fin.gamma = gamma; p.fin.dgamma = dgamma;
+    p.fin.dbeta = dbeta; p.fin.centered = 0;
+  }
   if (dz_early) { p.dout = dz_out; p.maskref = nullptr; p.dz_out = nullptr; }
   p.partial = dbias ? partial : nullptr;  // reuse (finalize already consumed it; stream-ordered)
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
@@ -1222,14 +1410,21 @@ int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void
   if (rows < 1 || rows > 512) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd_tail: %d partial rows (1..512)", rows);
   const int grid = bn_bwd_rows(dtype, M, C);
   float* bcoef = scratch + (size_t)(grid + ECG_TAIL_ROWS) * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, (double)M,
-                     gamma, coef, dgamma, dbeta, bcoef, 1);
-  ECG_CHECK_LAUNCH("bn_bwd_finalize");
+  const bool fold = ecg_bn_fold_ok(C, rows);   // (`partial` is the producer's buffer, never the apply pass's own rows)
+  if (!fold) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(1024), 0, stream, partial, rows, C, (double)M,
+                       gamma, coef, dgamma, dbeta, bcoef, 1);
+    ECG_CHECK_LAUNCH("bn_bwd_finalize");
+  }
   BnBwdParams p;
   memset(&p, 0, sizeof(p));
   p.dout = dout; p.maskref = maskref; p.y = y; p.coef = coef; p.M = M; p.C = C;
   p.gate = gate; p.addc = addc; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   p.bcoef = bcoef; p.dy = dy;
+  if (fold) {
+    p.fin.partial = partial; p.fin.rows = rows; p.fin.count = (double)M; p.fin.gamma = gamma; p.fin.dgamma = dgamma;
+    p.fin.dbeta = dbeta; p.fin.centered = 1;
+  }
   p.partial = dbias ? scratch : nullptr;   // (the finalize above reads `partial`, a different buffer: scratch's rows are free)
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");

@@ -68,6 +68,16 @@ int ecg_bn_finalize(const float* partial, int rows, int C, double count, const f
 int ecg_bn_eval_coef(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                      float* coef, hipStream_t stream);
 int ecg_col_stats(int dtype, const void* x, long M, int C, float* partial, int* rows_out, hipStream_t stream);
+// finalize folded into the consumer (elementwise.hip): the producer's partial rows + what bn_finalize needs
+struct EcgBnFold {
+  const float* partial; int rows; double count;
+  const float* gamma; const float* beta;
+  float* rm; float* rv; long long* nbt;   // running statistics (nullable)
+  float momentum, eps;
+};
+bool ecg_bn_fold_ok(int C, int rows);
+int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, const void* res, const float* rcoef,
+                    const float* gate, int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream);
 int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
                int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream);
 size_t ecg_bn_bwd_scratch(int dtype, long M, int C);

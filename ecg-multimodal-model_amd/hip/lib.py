@@ -92,6 +92,7 @@ SIGNATURES = {
     "ecgmm_bn_finalize": (i32, [vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp]),
     "ecgmm_bn_eval_coef": (i32, [i32, vp, vp, vp, vp, f32, vp, vp]),
     "ecgmm_bn_act": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, vp, i64, i32, vp]),
+    "ecgmm_bn_act_from_rows": (i32, [i32, vp, vp, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp, i64, i32, vp]),
     "ecgmm_bn_bwd_scratch": (sz, [i32, i64, i32]),
     "ecgmm_bn_bwd": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
     "ecgmm_conv_bwd_data_with_downsample": (i32, [i32, P(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "ecgmm_bnrelu_maxpool": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_maxpool_relu_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_bn_fuse_min_pixels": (i32, [i64]),
+    "ecgmm_bn_fold": (i32, [i32]),
     "ecgmm_stem_recompute": (i32, [i32]),
     "ecgmm_pool_bn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ecgmm_avgpool": (i32, [i32, vp, vp, i32, i32, i32, vp, vp]),

@@ -228,6 +228,13 @@ int ecgmm_bn_eval_coef(int C, const float* gamma, const float* beta, const float
  * (BasicBlock tail; BasicBlock1D tail with the SE gate, PMB:88-93) */
 int ecgmm_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
                  int rows_per_sample, int relu, void* out, int64_t M, int C, void* stream);
+/* ecgmm_bn_finalize + ecgmm_bn_act as ONE launch: every workgroup of the activation pass folds the (<= 512) partial rows
+ * itself -- no dependent finalize launch in between; workgroup 0 writes coef_out [4][C] (for the backward) and updates the
+ * running statistics.  More rows / unsupported widths fall back to the two launches.  Same values. */
+int ecgmm_bn_act_from_rows(int dtype, const void* y, const float* partial, int rows, double count, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float momentum, float eps, float* coef_out, const void* res, const float* rcoef,
+                           const float* gate, int rows_per_sample, int relu, void* out, int64_t M, int C, void* stream);
 /* BatchNorm backward with the ReLU mask / SE gate folded in:
  *   dz = [maskref > 0] * dout * gate[n][c] + addc[n][c];  dy, dgamma, dbeta; dz_out = masked dout;
  *   (maskref == y: the mask is recomputed as bn(y) > 0, saving the read of the activated tensor)
@@ -268,6 +275,10 @@ int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, con
  * least this many output pixels (default 400000 = the 56x56 stage at batch >= 128; 0 = wherever the halo kernel runs;
  * negative restores the default).  Start-up value: ECGMM_BN_FUSE_MIN_M.  Results differ by fp32 summation order only. */
 int ecgmm_bn_fuse_min_pixels(int64_t m);
+/* BatchNorm finalize folded into its consumer pass (every workgroup of bn_act / the backward's apply pass folds the <= 512
+ * partial rows itself instead of a separate ~5 us launch in between; csrc/elementwise.hip): 1 = on (default), 0 = separate
+ * launches.  Start-up value: ECGMM_BN_FOLD.  Same values up to the fp64 summation grouping of the partial rows. */
+int ecgmm_bn_fold(int on);
 /* ResNet18 plan: run the stem by recompute (ecgmm_stem_stats_only / stem_pool_fwd / stem_pool_bwd; bf16 only): 1 = on,
  * 0 = the two-pass route that keeps the full-resolution conv output (default: 0.2 ms per step faster at batch 256 although
  * it moves 1.6 GB more -- the recomputing kernels are instruction-bound).  Start-up value: ECGMM_STEM_RECOMPUTE.

@@ -303,6 +303,73 @@ def test_fused_reduction_row_count_follows_the_halo_cu_cap(cap):
         assert rel_err(u, v) < 1e-5
 
 
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16, 256), (2, 128, 8, 8, 37), (3, 256, 5, 4, 512), (2, 512, 4, 4, 64)])
+def test_finalize_folded_into_the_consumer_pass(dt, shape):
+    """ecgmm_bn_act_from_rows == ecgmm_bn_finalize + ecgmm_bn_act, and ecgmm_bn_bwd with the fold (default) == without
+    (ecgmm_bn_fold(0)): outputs, coefficients, running statistics, dgamma / dbeta.  Every workgroup of the consumer folds the
+    partial rows itself (csrc/elementwise.hip); the rows here are synthetic multi-row splits of the true column sums."""
+    N, Cn, H, W, rows = shape
+    lib = L.lib()
+    M = N * H * W
+    x = fill.hash_tensor((N, Cn, H, W), 71, 1.5) + 0.2
+    res = fill.hash_tensor((N, Cn, H, W), 72)
+    if dt == L.BF16:
+        x, res = bf16_round(x), bf16_round(res)
+    gam, bet = dev(1 + 0.3 * fill.hash_tensor((Cn,), 73)), dev(0.2 * fill.hash_tensor((Cn,), 74))
+    xg, rg = to_nhwc(x, dt), to_nhwc(res, dt)
+    # partial rows: the column sums split over `rows` rows with hash weights that add up to 1
+    wgt = (fill.hash_tensor((rows, 1), 75).abs() + 0.1)
+    wgt = dev(wgt / wgt.sum())
+    col = torch.stack([x.sum(dim=(0, 2, 3)), (x * x).sum(dim=(0, 2, 3))]).to(DEV)            # [2][C]
+    part = (wgt[:, :, None] * col[None]).contiguous()                                            # [rows][2][C]
+    part = torch.cat([part, torch.zeros(64, 2, Cn, device=DEV)])
+
+    def fwd(folded):
+        rm, rv, nbt = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        coef = torch.full((4, Cn), float("nan"), device=DEV)
+        out = torch.empty(M * Cn, device=DEV, dtype=TDT[dt])
+        if folded:
+            L.check(lib.ecgmm_bn_act_from_rows(dt, ptr(xg), ptr(part), rows, float(M), ptr(gam), ptr(bet), ptr(rm), ptr(rv),
+                                               ptr(nbt), 0.1, 1e-5, ptr(coef), ptr(rg), None, None, 1, 1, ptr(out), M, Cn, stream()))
+        else:
+            L.check(lib.ecgmm_bn_finalize(ptr(part), rows, Cn, float(M), ptr(gam), ptr(bet), ptr(rm), ptr(rv), ptr(nbt), 0.1,
+                                          1e-5, ptr(coef), stream()))
+            L.check(lib.ecgmm_bn_act(dt, ptr(xg), ptr(coef), ptr(rg), None, None, 1, 1, ptr(out), M, Cn, stream()))
+        torch.cuda.synchronize()
+        return out.float().cpu(), coef.cpu(), rm.cpu(), rv.cpu(), int(nbt)
+
+    a, b = fwd(True), fwd(False)
+    assert a[4] == b[4] == 1
+    for u, v in zip(a[1:4], b[1:4]):
+        assert torch.allclose(u, v, rtol=1e-6, atol=1e-7), float((u - v).abs().max())
+    assert rel_err(a[0], b[0]) < (1e-6 if dt == L.F32 else 2e-3)
+    # backward: the same call with and without the fold
+    dy = fill.hash_tensor((N, Cn, H, W), 76)
+    if dt == L.BF16:
+        dy = bf16_round(dy)
+    dyg = to_nhwc(dy, dt)
+    coef = dev(b[1])
+    scratch = torch.empty(lib.ecgmm_bn_bwd_scratch(dt, M, Cn), device=DEV, dtype=torch.uint8)
+
+    def bwd(fold):
+        lib.ecgmm_bn_fold(fold)
+        dx = torch.empty(M * Cn, device=DEV, dtype=TDT[dt])
+        dgam, dbet = torch.full((Cn,), float("nan"), device=DEV), torch.full((Cn,), float("nan"), device=DEV)
+        L.check(lib.ecgmm_bn_bwd(dt, ptr(dyg), ptr(xg), None, None, 1, ptr(xg), ptr(coef), ptr(gam), ptr(dgam), ptr(dbet),
+                                 ptr(dx), None, None, M, Cn, ptr(scratch), stream()))
+        torch.cuda.synchronize()
+        return dx.float().cpu(), dgam.cpu(), dbet.cpu()
+
+    try:
+        c, d = bwd(1), bwd(0)
+    finally:
+        lib.ecgmm_bn_fold(1)
+    assert torch.equal(c[1], d[1]) or torch.allclose(c[1], d[1], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(c[2], d[2], rtol=1e-6, atol=1e-6)
+    assert rel_err(c[0], d[0]) < (1e-6 if dt == L.F32 else 2e-3)
+
+
 def test_conv_rejects_bad_shapes():
     lib = L.lib()
     d = conv_desc(1, 8, 8, 6, 64, 3, 3, 1, 1, 1)   # Cin not a multiple of the 16-byte vector
