@@ -1289,7 +1289,9 @@ extern "C" int ecgmm_bn_fold(int on) {
   return 0;
 }
 bool ecg_bn_fold_ok(int C, int rows) {
-  if (g_bn_fold < 0) { const char* e = getenv("ECGMM_BN_FOLD"); g_bn_fold = !(e && e[0] == '0'); }
+  // DEFAULT OFF: same-call A/B at batch 256 (round 3): 6.98 ms with the separate launches, 7.04 ms folded -- 256 workgroups
+  // each re-reading the same 128-256 KB of partial rows cost the L2 what the ~5 us launch + its boundary cost the stream.
+  if (g_bn_fold < 0) { const char* e = getenv("ECGMM_BN_FOLD"); g_bn_fold = (e && e[0] == '1'); }
   if (!g_bn_fold || rows < 1 || rows > 512 || C > 512) return false;
   return C >= 128 ? C % 128 == 0 : (C >= 16 && 1024 % C == 0);
 }

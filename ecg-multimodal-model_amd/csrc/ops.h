@@ -195,6 +195,7 @@ enum { ECG_PROF_IGEMM_FWD = 0, ECG_PROF_IGEMM_DGRAD = 1, ECG_PROF_WGRAD = 2, ECG
        ECG_PROF_IGEMM_F32_FWD = 5, ECG_PROF_IGEMM_F32_DGRAD = 6 };  // exact-fp32 instantiation (other MFMA peak): own kinds
 void ecg_prof_begin(int kind, double flops, double bytes, hipStream_t s);
 void ecg_prof_end(hipStream_t s);
+void ecg_tl_mark(int id, hipStream_t s);   // diagnostic step timeline (prof.hip); ids: 100 + k forward, 200 + k backward
 
 // bump allocator over a caller-owned workspace (base == nullptr: measure only)
 struct Arena {

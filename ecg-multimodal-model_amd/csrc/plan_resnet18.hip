@@ -323,6 +323,7 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
   static const bool down_side_on = [] { const char* e = getenv("ECGMM_DOWN_SIDE"); return !(e && e[0] == '0'); }();
   const bool side_fwd = g_side.enabled && down_side_on;
 
+  ecg_tl_mark(100, s);
   // ---- every conv weight -> compute-dtype operand layouts, one launch.  (Running it on the side stream underneath
   // the stem convolution was measured: no gain -- a cross-stream event wait costs 35-140 us of GPU-side latency on
   // this platform, more than the 0.1 ms pack hides.)
@@ -354,6 +355,7 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
     ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
   }
 
+  ecg_tl_mark(101, s);
   const void* cur = w.p0;
   for (int i = 0; i < 8; ++i) {
     const BlockCfg& k = r.blk[i];
@@ -396,11 +398,13 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
                           nullptr, b.out, s));
     }
     cur = b.out;
+    ecg_tl_mark(102 + i, s);
   }
   const BlockCfg& last = r.blk[7];
   ECG_TRY(ecg_avgpool(dt, cur, w.pooled, N, last.hout * last.wout, 512, nullptr, s));
   ECG_TRY(ecg_linear_fwd(w.pooled, P(params, r.p_fc), P(params, r.p_fc + 1), feat_out, N, 512, r.d.out_dim, 0, nullptr,
                          s));
+  ecg_tl_mark(110, s);
   return 0;
 }
 
@@ -426,7 +430,9 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   struct NarrowOff { ~NarrowOff() { ecg_conv_wgrad_narrow(false); } } narrow_off;
   hipStream_t ws = side ? g_side.s : s;  // stream of the weight-gradient kernels
 
+  if (stage_begin == 0) ecg_tl_mark(200, s);
   for (int st = stage_begin; st < stage_end; ++st) {
+    if (st > 0) ecg_tl_mark(200 + st, s);   // (mark 200 + st = stage st - 1 enqueued behind it: fc = 201, blocks 7..0 = 202..209)
     if (st == 0) {
       g_side.doneA = g_side.doneB = g_side.doneC = nullptr;
       for (int a = 0; a < 3; ++a) g_side.done2[a][0] = g_side.done2[a][1] = nullptr;
@@ -562,11 +568,13 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       ECG_FAIL(ECGMM_ERR_SHAPE, "resnet18 bwd: stage %d out of range", st);
     }
   }
+  if (stage_end == 10) ecg_tl_mark(210, s);
   if (side && !g_side.defer_join) {  // join: everything the side stream did is ordered before whatever the caller enqueues next
     hipEvent_t e = side_next_ev();
     (void)hipEventRecord(e, g_side.s);
     (void)hipStreamWaitEvent(s, e, 0);
   }
+  if (stage_end == 10) ecg_tl_mark(211, s);
   return 0;
 }
 

@@ -67,3 +67,45 @@ extern "C" int ecgmm_prof_collect(int nkinds, double* ms, double* flops, double*
   g_n = 0;
   return n >= MAXEV ? ECGMM_ERR_WORKSPACE : 0;
 }
+
+// ---- step timeline (diagnostic): timestamped marks on the caller's stream at the plans' phase boundaries, read back as
+// milliseconds since the first mark.  Off by default (one branch per mark).
+namespace {
+constexpr int TLMAX = 4096;
+bool g_tl_on = false, g_tl_created = false;
+int g_tl_n = 0;
+hipEvent_t g_tl_ev[TLMAX];
+int g_tl_id[TLMAX];
+}  // namespace
+void ecg_tl_mark(int id, hipStream_t s) {
+  if (!g_tl_on || g_tl_n >= TLMAX) return;
+  g_tl_id[g_tl_n] = id;
+  (void)hipEventRecord(g_tl_ev[g_tl_n++], s);
+}
+extern "C" int ecgmm_tl_enable(int on) {
+  if (on && !g_tl_created) {
+    for (int i = 0; i < TLMAX; ++i)
+      if (hipEventCreate(&g_tl_ev[i]) != hipSuccess) ECG_FAIL(ECGMM_ERR_LAUNCH, "timeline: hipEventCreate failed");
+    g_tl_created = true;
+  }
+  g_tl_on = on != 0;
+  g_tl_n = 0;
+  return 0;
+}
+extern "C" int ecgmm_tl_mark(int id, void* stream) {
+  ecg_tl_mark(id, (hipStream_t)stream);
+  return 0;
+}
+// ids[i], ms[i] (since mark 0) for up to `cap` marks; returns the number of marks recorded
+extern "C" int ecgmm_tl_collect(int cap, int* ids, float* ms) {
+  int n = g_tl_n < cap ? g_tl_n : cap;
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventSynchronize(g_tl_ev[i]);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, g_tl_ev[0], g_tl_ev[i]);
+    ids[i] = g_tl_id[i];
+    ms[i] = t;
+  }
+  g_tl_n = 0;
+  return n;
+}

@@ -103,6 +103,9 @@ SIGNATURES = {
     "ecgmm_maxpool_relu_bwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ecgmm_bn_fuse_min_pixels": (i32, [i64]),
     "ecgmm_bn_fold": (i32, [i32]),
+    "ecgmm_tl_enable": (i32, [i32]),
+    "ecgmm_tl_mark": (i32, [i32, vp]),
+    "ecgmm_tl_collect": (i32, [i32, vp, vp]),
     "ecgmm_stem_recompute": (i32, [i32]),
     "ecgmm_pool_bn_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ecgmm_avgpool": (i32, [i32, vp, vp, i32, i32, i32, vp, vp]),

@@ -407,6 +407,13 @@ int ecgmm_prof_enable(int on);
 /* pause(1) suspends the bracketing, pause(0) resumes it; recorded launches are kept (bench.py samples steps). */
 int ecgmm_prof_pause(int paused);
 int ecgmm_prof_collect(int nkinds, double* ms, double* flops, double* bytes, int64_t* count);
+/* Diagnostic step timeline: with ecgmm_tl_enable(1) the ResNet18 plan records a timestamped event on the caller's stream at
+ * every phase boundary (ids 100.. forward: 100 start, 101 stem, 102..109 blocks, 110 end; 200.. backward: 200 start, 201 fc,
+ * 202..209 blocks 7..0, 210 stem, 211 joined); ecgmm_tl_mark adds the host's own marks; ecgmm_tl_collect returns ids and
+ * milliseconds since the first mark and clears the list. */
+int ecgmm_tl_enable(int on);
+int ecgmm_tl_mark(int id, void* stream);
+int ecgmm_tl_collect(int cap, int* ids, float* ms);
 
 #ifdef __cplusplus
 }

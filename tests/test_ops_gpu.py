@@ -325,6 +325,8 @@ def test_finalize_folded_into_the_consumer_pass(dt, shape):
     part = (wgt[:, :, None] * col[None]).contiguous()                                            # [rows][2][C]
     part = torch.cat([part, torch.zeros(64, 2, Cn, device=DEV)])
 
+    lib.ecgmm_bn_fold(1)       # (ecgmm_bn_act_from_rows falls back to two launches when the fold is switched off)
+
     def fwd(folded):
         rm, rv, nbt = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
         coef = torch.full((4, Cn), float("nan"), device=DEV)
@@ -364,7 +366,7 @@ def test_finalize_folded_into_the_consumer_pass(dt, shape):
     try:
         c, d = bwd(1), bwd(0)
     finally:
-        lib.ecgmm_bn_fold(1)
+        lib.ecgmm_bn_fold(0)
     assert torch.equal(c[1], d[1]) or torch.allclose(c[1], d[1], rtol=1e-6, atol=1e-6)
     assert torch.allclose(c[2], d[2], rtol=1e-6, atol=1e-6)
     assert rel_err(c[0], d[0]) < (1e-6 if dt == L.F32 else 2e-3)
