@@ -110,7 +110,7 @@ def test_cfg3_full_multimodal_batch256_vs_oracle():
             "image_encoder.layer4.1.conv2.weight", "image_encoder.fc.weight", "signal_encoder.initial.0.weight",
             "signal_encoder.layer3.conv2.weight", "clinical_encoder.0.weight", "fusion_classifier.0.weight",
             "attention_fusion.weights"]
-    _check(make_ref, make_net, (img, sig, clin), loss_of, keys, 1e-2, 5e-2, 0.6)
+    _check(make_ref, make_net, (img, sig, clin), loss_of, keys, 1e-2, 3.5e-2, 0.6)     # measured 0.0156 / 0.42 (torch autocast: 0.0172)
 
 
 def test_cfg2_image_only_batch128_vs_oracle():
@@ -130,7 +130,7 @@ def test_cfg2_image_only_batch128_vs_oracle():
 
     keys = ["image_encoder.conv1.weight", "image_encoder.layer1.0.conv1.weight", "image_encoder.layer3.0.conv1.weight",
             "image_encoder.layer4.1.conv2.weight", "image_encoder.fc.weight", "image_encoder.fc.bias"]
-    _check(make_ref, make_net, (img,), loss_of, keys, 1e-2, 5e-2, 0.6)
+    _check(make_ref, make_net, (img,), loss_of, keys, 1e-2, 4.5e-2, 0.6)              # measured 0.0229 / 0.44 (torch autocast: 0.0233)
 
 
 def test_cfg5_signal12_batch512_focal_vs_oracle():
@@ -152,4 +152,4 @@ def test_cfg5_signal12_batch512_focal_vs_oracle():
 
     keys = ["initial.0.weight", "layer1.conv1.weight", "layer2.downsample.0.weight", "layer3.conv2.weight",
             "layer3.se.fc.0.weight", "classifier.1.weight", "classifier.4.weight"]
-    _check(make_ref, make_net, (x,), loss_of, keys, 1e-2, 5e-2, 0.6)
+    _check(make_ref, make_net, (x,), loss_of, keys, 1e-2, 4e-3, 0.3)                  # measured 0.0012 / 0.15 (torch autocast: 0.0053)
