@@ -54,6 +54,7 @@ struct HaloParams {
   int hrows;  // 256 + 2 * HL
   int ntm;    // pixel tiles (M / 256)
   int ntn;    // channel tiles (Cd / BN); gridDim.x is a multiple of it
+  int stagger;  // 1: waves 4-7 run their first MFMA block of a step AFTER the step's barrier (see slice())
 };
 
 __device__ __forceinline__ void hdma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_wave_base, unsigned voffset,
@@ -133,6 +134,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wv & 3, wc = wv >> 2;   // (NW == 4: wc == 0)
+  // (64-channel tiles only -- measured stand-alone, batch 256: layer 1 forward 97.8 -> 91.2 us, input gradient 94.3 -> 88.9 us;
+  // the 128-channel tiles of layers 2-4 got 3-5 % SLOWER with it (their two MFMA blocks per step already fill the interval,
+  // and the branch cost them registers: 12 -> 52 B of scratch), so they stay in lock step)
+  const bool late = NW == 8 && BN == 64 && p.stagger != 0 && wv >= 4;
   // weight ring slot of K step g (tap t): 4 slots -> g & 3; 3 slots -> t % 3 (every slice has RS = 3 or 9 steps)
   auto slot_of = [](int g, int t) -> int { return C::NWS == 4 ? (g & 3) : (t % 3); };
   auto hbuf_of = [](int q) -> unsigned { return C::NHB == 2 ? (unsigned)(q & 1) * C::HBUF : 0u; };
@@ -308,6 +313,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 
   // One channel slice = RS steps, fully unrolled and branch-free, so that every wait count is a compile-time constant
   // and hipcc's LDS-read bookkeeping stays exact.  LAST = the tile's last slice: no fills past the tile's end.
+  // LATE (round 3, the guide's "two waves that run the same program with one barrier per block: try a stagger"): the two
+  // waves of a SIMD (w and w + 4) otherwise reach their MFMA blocks, their fragment reads, the fill issue and the barrier
+  // together -- the matrix pipe serves both at once and then neither.  Waves 4-7 therefore run the step's first MFMA block
+  // AFTER the step's barrier instead of before it: right behind a barrier they issue MFMAs while waves 0-3 issue fragment
+  // reads, and in front of the next one they issue reads / fills while waves 0-3 finish their MFMA block.  Same
+  // instructions, same barriers and wait counts, same results bit for bit.
+  // (A wave-uniform branch around the one MFMA block, not two copies of the slice: duplicating the slice pushed the 128-channel
+  // instantiations into scratch.  Both paths leave the same LDS reads pending at the joins, so hipcc's wait bookkeeping stays exact.)
   auto slice = [&](int cs, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     const unsigned hb = hbuf_of(qs), hbn = hbuf_of(qs + 1);
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
       if (n_halo(t, LAST) > 0) dma_halo(hbn, NCS1 ? 0 : cs + 1, t * HPS, (t + 1) * HPS);   // (NCS1: the next TILE's halo, hoff set at the tile's start)
 #endif
       // (c) k-step 0
-      mma(fa0, fb0);
+      if (!late) mma(fa0, fb0);
       // (d) the fills of step s + 1 (issued two steps ago) have landed -- this wave's, then (barrier) everybody's; all that
       // may still be in flight are the previous step's and this step's fills.  (The step before a slice's first one is a
       // non-final slice's last step, or the tile prologue, whose fills were all waited for: a larger count is then moot.)
@@ -367,6 +380,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #if !(defined(HALO_ABL) && HALO_ABL == 5)   // diagnostic 5: no per-step barrier
       __builtin_amdgcn_s_barrier();
 #endif
+      if (late) mma(fa0, fb0);
       // (e) k-step 0 of the next step (none after the tile's last step)
       if (!(LAST && t == RS - 1)) {
         const int t1 = (t + 1) % RS;
@@ -407,8 +421,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
       for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, 0) + hb);
     }
-    for (int cs = 0; cs + 1 < p.ncs; ++cs) slice(cs, std::integral_constant<bool, false>{});
-    slice(p.ncs - 1, std::integral_constant<bool, true>{});
+    using F_ = std::integral_constant<bool, false>;
+    using T_ = std::integral_constant<bool, true>;
+    for (int cs = 0; cs + 1 < p.ncs; ++cs) slice(cs, F_{});
+    slice(p.ncs - 1, T_{});
     // every wave is past the last step's barrier, i.e. has read its last fragments: the halo buffer and the weight
     // slots the next tile starts with are free; its fills are issued from inside this tile's epilogue (below)
     // the K loop ends HERE for every accumulator (hipcc otherwise sinks the last slice's MFMAs of the second pixel half
@@ -725,6 +741,7 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
 // compiler-inserted scratch traffic inside the counted-vmcnt K loop its partial rows were NOT reproducible run to run once
 // other streams shared the GPU (tools/det_check_mm.py; every scratch-free instantiation is bit-reproducible).
 int g_halo_w4 = -1;
+int g_halo_stagger = -1;  // waves 4-7 staggered by one MFMA block (-1: read ECGMM_HALO_STAGGER, default on)
 int g_halo_enabled = -1;  // read once from ECGMM_CONV_HALO: 0 = off, 1 = where it is the faster kernel (default), 2 = wherever applicable
 
 }  // namespace
@@ -735,6 +752,10 @@ extern "C" int ecgmm_conv_halo_enable(int on) {
   return 0;
 }
 
+extern "C" int ecgmm_conv_halo_stagger(int on) {
+  g_halo_stagger = on != 0;
+  return 0;
+}
 extern "C" int ecgmm_conv_halo_w4(int on) {
   g_halo_w4 = on != 0;
   return 0;
@@ -801,6 +822,8 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
       p.red_rows = epi->red_rows;
     }
   }
+  if (g_halo_stagger < 0) { const char* e = getenv("ECGMM_HALO_STAGGER"); g_halo_stagger = !(e && e[0] == '0'); }
+  p.stagger = g_halo_stagger;
   int wg = 0;
   const bool wide = p.Cd > 64;
   int rc;

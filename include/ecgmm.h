@@ -166,6 +166,10 @@ int ecgmm_conv_halo_cus(int cus);
  * workgroup per CU: 0 = off (default: faster stand-alone, slower inside the overlapped step), 1 = on.
  * Start-up value: ECGMM_HALO_W4. */
 int ecgmm_conv_halo_w4(int on);
+/* Halo conv kernel: waves 4-7 of the 8-wave workgroup run each step's first MFMA block behind the step's barrier instead of
+ * in front of it, so the two waves of a SIMD alternate between the matrix pipe and the LDS / fill issue instead of meeting
+ * there: 1 = on (default), 0 = lock step.  Pure scheduling (bit-identical results).  Start-up value: ECGMM_HALO_STAGGER. */
+int ecgmm_conv_halo_stagger(int on);
 /* Weight gradients of the same stride-1 3x3 / 1x3 bf16 convolutions keep their x operand in an LDS ring of pixel rows
  * (wgrad_ring_kernel, csrc/conv_wgrad.hip) instead of one gathered tile per filter tap: 0 = never, 1 = for the shapes
  * it is faster on (default), 2 = wherever applicable (A/B, tests).  Start-up value: ECGMM_WGRAD_RING=0|1|2. */
