@@ -65,6 +65,11 @@ int ecgmm_stem_fwd(int dtype, const float* x, const void* packed, const float* b
                    int Cin, int H, int W, int R, void* stream) {
   return ecg_stem_fwd(dtype, x, packed, bias, y, stats, N, Cin, H, W, R, S_(stream));
 }
+int ecgmm_stem_wg_stats_rows(int N, int Cin, int H, int W, int R) { return ecg_stem_wg_stats_rows(N, Cin, H, W, R); }
+int ecgmm_stem_fwd_wgrows(int dtype, const float* x, const void* packed, const float* bias, void* y, float* stats, int N,
+                          int Cin, int H, int W, int R, void* stream) {
+  return ecg_stem_fwd_wgrows(dtype, x, packed, bias, y, stats, N, Cin, H, W, R, S_(stream));
+}
 int ecgmm_stem_stats_only_rows(int N, int Cin, int H, int W, int R) { return ecg_stem_stats_only_rows(N, Cin, H, W, R); }
 int ecgmm_stem_stats_only(int dtype, const float* x, const void* packed, const float* bias, float* stats, int N, int Cin,
                           int H, int W, int R, void* stream) {

@@ -107,8 +107,12 @@ __device__ __forceinline__ int stem_xcd_order() {
 // no output store, and the sums stay in registers across the workgroup's images (a workgroup keeps one tile position):
 // one set of four statistics rows per WORKGROUP, written at the end, instead of one per tile (128 DPP adds per
 // wave-tile and 13x the rows for the finalize to fold).
-template <typename T, int R, bool STATS_ONLY = false>
+// SMODE 2 (round 3): the ordinary forward (output stored) with the same per-workgroup statistics rows: the per-tile form
+// spent ~30 % of a wave-tile's ~1 000 instructions on 128 DPP adds + row stores (ablation: 49 of 249 us), and its 100 k
+// rows needed a fold launch in front of the finalize.  SMODE 0 keeps the per-tile rows of the stand-alone C entry point.
+template <typename T, int R, int SMODE = 0>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
+  constexpr bool STATS_ONLY = SMODE == 1, STATS_WG = SMODE != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TH = StemDims<R>::TH, TW = StemDims<R>::TW, PH = StemDims<R>::PH, PWS = StemDims<R>::PWS;
   constexpr int NPRE = StemDims<R>::NPRE, PB = NPRE * 256;  // elements per patch buffer
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   // Two patch buffers: the next image's patch is fetched into registers at the top of a tile and written to the
   // OTHER buffer between this tile's MFMA loop and its epilogue, so the wait for those loads does not also wait for
   // the previous epilogue's output stores (stores and loads share vmcnt), and a tile needs one barrier, not two.
-  float ws1[STATS_ONLY ? 4 : 1][4], ws2[STATS_ONLY ? 4 : 1][4];   // STATS_ONLY: per-lane sums over all of the workgroup's tiles
-  if (STATS_ONLY) {
+  float ws1[STATS_WG ? 4 : 1][4], ws2[STATS_WG ? 4 : 1][4];   // per-lane sums over all of the workgroup's tiles
+  if (STATS_WG) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -307,7 +311,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
         opk[a - ap][b].y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
       }
     }
-    if (p.stats && (STEM_ABL != 2 || p.N < 0)) {
+    if (STATS_WG) {
+      if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ws1[a][j] += s1[j];
+          ws2[a][j] += s2[j];
+        }
+      }
+    } else if (p.stats && (STEM_ABL != 2 || p.N < 0)) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s1[j] = row16_sum(s1[j]);
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }  // channel-tile pairs
   __syncthreads();  // the other buffer is complete; everyone is done reading this one
   }  // image loop
-  if constexpr (STATS_ONLY) {
+  if (STATS_WG && p.stats) {
     // rows [blockIdx.x * 4 + wave][2][64]: 16-lane DPP sums once per workgroup
     float* srow = p.stats + ((size_t)blockIdx.x * 4 + wave) * 2 * STEM_CO;
 #pragma unroll
@@ -603,8 +615,20 @@ int ecg_stem_pack(int dtype, const float* w, void* out, int Cin, int R, hipStrea
   return 0;
 }
 
+// rows of the per-workgroup statistics form (ecg_stem_fwd_wgrows): 4 per workgroup
+int ecg_stem_wg_stats_rows(int N, int Cin, int H, int W, int R) { return ecg_stem_stats_only_rows(N, Cin, H, W, R); }
+static int stem_fwd_impl(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
+                         int H, int W, int R, bool wg_rows, hipStream_t stream);
+int ecg_stem_fwd_wgrows(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
+                        int H, int W, int R, hipStream_t stream) {
+  return stem_fwd_impl(dtype, x, wpk, bias, y, stats, N, Cin, H, W, R, true, stream);
+}
 int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
                  int H, int W, int R, hipStream_t stream) {
+  return stem_fwd_impl(dtype, x, wpk, bias, y, stats, N, Cin, H, W, R, false, stream);
+}
+static int stem_fwd_impl(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
+                         int H, int W, int R, bool wg_rows, hipStream_t stream) {
   StemShape s;
   ECG_TRY(stem_shape(Cin, H, W, R, s));
   StemParams p;
@@ -620,7 +644,12 @@ int ecg_stem_fwd(int dtype, const float* x, const void* wpk, const float* bias, 
   dim3 grid(tpi * nslots);
   ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7,
                  4.0 * N * Cin * H * W + (double)dtype_size(dtype) * N * s.OH * s.OW * STEM_CO, stream);
-  if (dtype == ECGMM_BF16) {
+  if (dtype == ECGMM_BF16 && wg_rows) {
+    if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7, 2>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1, 2>), grid, dim3(256), lds, stream, p);
+  } else if (wg_rows) {
+    ECG_FAIL(ECGMM_ERR_DTYPE, "stem: per-workgroup statistics rows are a bf16 form");
+  } else if (dtype == ECGMM_BF16) {
     if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7>), grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1>), grid, dim3(256), lds, stream, p);
   } else if (dtype == ECGMM_F32) {
@@ -663,8 +692,8 @@ int ecg_stem_stats_only(int dtype, const float* x, const void* wpk, const float*
   size_t lds = align_up((size_t)STEM_CO * WS * 2, 16) + 2 * stem_patch_buffer_bytes(R, 2);
   dim3 grid(stem_stats_grid(N, s.tiles_h * s.tiles_w));
   ecg_prof_begin(ECG_PROF_STEM_FWD, 2.0 * (double)N * s.OH * s.OW * STEM_CO * Cin * R * 7, 4.0 * N * Cin * H * W, stream);
-  if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7, true>), grid, dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1, true>), grid, dim3(256), lds, stream, p);
+  if (R == 7) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 7, 1>), grid, dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, 1, 1>), grid, dim3(256), lds, stream, p);
   ecg_prof_end(stream);
   ECG_CHECK_LAUNCH("stem_stats_only");
   return 0;

@@ -47,6 +47,9 @@ size_t ecg_stem_wgrad_workspace(int N, int Cin, int H, int W, int R);
 int ecg_stem_wgrad(int dtype, const float* x, const void* dy, float* grad, int accumulate, void* workspace,
                    size_t workspace_bytes, int N, int Cin, int H, int W, int R, hipStream_t stream);
 int ecg_stem_stats_only_rows(int N, int Cin, int H, int W, int R);
+int ecg_stem_wg_stats_rows(int N, int Cin, int H, int W, int R);
+int ecg_stem_fwd_wgrows(int dtype, const float* x, const void* wpk, const float* bias, void* y, float* stats, int N, int Cin,
+                        int H, int W, int R, hipStream_t stream);   // bf16: statistics rows per workgroup (4 x grid) instead of per tile
 int ecg_stem_stats_only(int dtype, const float* x, const void* wpk, const float* bias, float* stats, int N, int Cin, int H,
                         int W, int R, hipStream_t stream);
 int ecg_stem_wgrad_reduce(const float* slab, float* grad, int rows, int NG, int accumulate, hipStream_t stream);

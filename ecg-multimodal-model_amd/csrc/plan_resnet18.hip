@@ -349,9 +349,16 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
                     buffers, 0, w.coef0, s));
     ECG_TRY(ecg_stem_pool_fwd(image, w.wstem, w.coef0, w.p0, w.idx0, N, 3, r.d.H, r.d.W, s));
   } else {
-    ECG_TRY(ecg_stem_fwd(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
-    ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
-                    buffers, 0, w.coef0, s));
+    // (bf16: statistics rows per workgroup -- sums kept in registers across the workgroup's tiles -- instead of per tile)
+    if (dt == ECGMM_BF16) {
+      ECG_TRY(ecg_stem_fwd_wgrows(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
+      ECG_TRY(bn_coef(r, w.stats, ecg_stem_wg_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
+                      buffers, 0, w.coef0, s));
+    } else {
+      ECG_TRY(ecg_stem_fwd(dt, image, w.wstem, nullptr, w.y0, stats_rows ? w.stats : nullptr, N, 3, r.d.H, r.d.W, 7, s));
+      ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, 3, r.d.H, r.d.W, 7), 64, (long)N * r.H1 * r.W1, params, 1,
+                      buffers, 0, w.coef0, s));
+    }
     ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, r.H1, r.W1, 64, s));
   }
 

@@ -262,9 +262,16 @@ extern "C" int ecgmm_resnet1d_forward(const ecgmm_resnet1d_desc* d, const float*
     ECG_TRY(ecg_pack_weight_batch(dt, items, n, s));
   }
   ECG_TRY(ecg_stem_pack(dt, P(params, 0), w.wstem, cin, 1, s));
-  ECG_TRY(ecg_stem_fwd(dt, signal, w.wstem, P(params, 1), w.y0, st, N, cin, 1, r.d.L, 1, s));
-  ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, cin, 1, r.d.L, 1), 64, (long)N * r.L1, params, 2, buffers, 0,
-                  w.coef0, s));
+  // (bf16: statistics rows per workgroup -- sums kept in registers across the workgroup's tiles -- instead of per tile)
+  if (dt == ECGMM_BF16) {
+    ECG_TRY(ecg_stem_fwd_wgrows(dt, signal, w.wstem, P(params, 1), w.y0, st, N, cin, 1, r.d.L, 1, s));
+    ECG_TRY(bn_coef(r, w.stats, ecg_stem_wg_stats_rows(N, cin, 1, r.d.L, 1), 64, (long)N * r.L1, params, 2, buffers, 0,
+                    w.coef0, s));
+  } else {
+    ECG_TRY(ecg_stem_fwd(dt, signal, w.wstem, P(params, 1), w.y0, st, N, cin, 1, r.d.L, 1, s));
+    ECG_TRY(bn_coef(r, w.stats, ecg_stem_stats_rows(N, cin, 1, r.d.L, 1), 64, (long)N * r.L1, params, 2, buffers, 0,
+                    w.coef0, s));
+  }
   ECG_TRY(ecg_bnrelu_maxpool(dt, w.y0, w.coef0, w.p0, w.idx0, N, 1, r.L1, 64, s));
 
   const void* cur = w.p0;

@@ -1,8 +1,10 @@
 // Library-owned side stream for the weight-gradient kernels of an encoder's backward.
 // wgrad only feeds the optimizer, so it is taken off the critical path dgrad -> BN-backward -> dgrad: it runs on a
-// HIP stream owned by the library, forked from / joined to the caller's stream with events (all asynchronous and
-// capturable; a call joins before it returns unless the caller asked to defer that, so to the caller the work is still
-// ordered on the stream it passed).  MFMA-bound wgrad overlaps the HBM-bound BatchNorm passes.  Each encoder plan has
+// HIP stream owned by the library, forked from / joined to the caller's stream with events (all asynchronous; a call joins
+// before it returns unless the caller asked to defer that, so to the caller the work is still ordered on the stream it
+// passed).  NOT supported under hipGraph stream capture: the plans' launch paths query device properties / set function
+// attributes behind first-use guards and record events on this library-owned (non-capturing) stream; a whole-step capture
+// attempted in round 2 faulted inside capture and was dropped (the step is not launch-bound: host enqueue 3.1 ms vs 7 ms GPU).  MFMA-bound wgrad overlaps the HBM-bound BatchNorm passes.  Each encoder plan has
 // its own instance: the two encoders of the multimodal model run concurrently and must not couple through one stream.
 #pragma once
 #include <cstdlib>

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ecgmm_stem_stats_rows": (i32, [i32, i32, i32, i32, i32]),
     "ecgmm_stem_pack": (i32, [i32, vp, vp, i32, i32, vp]),
     "ecgmm_stem_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ecgmm_stem_wg_stats_rows": (i32, [i32, i32, i32, i32, i32]),
+    "ecgmm_stem_fwd_wgrows": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ecgmm_stem_stats_only_rows": (i32, [i32, i32, i32, i32, i32]),
     "ecgmm_stem_stats_only": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ecgmm_stem_pool_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

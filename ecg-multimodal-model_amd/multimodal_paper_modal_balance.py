@@ -42,7 +42,10 @@ class SEBlock(nn.Module):
         )
 
     def forward(self, x):
-        raise RuntimeError("SEBlock is executed by ResNet1D_SE's fused launch plan; call the encoder")
+        """x * sigmoid(fc(mean_L x)) on the per-op kernels (ecgmm/hip/blocks.py).  Stand-alone use only -- inside
+        ``ResNet1D_SE`` the encoder's launch plan runs the block; no autograd graph is built here."""
+        from .hip import blocks
+        return blocks.se_block_forward(self, x)
 
 
 class BasicBlock1D(nn.Module):
@@ -64,8 +67,14 @@ class BasicBlock1D(nn.Module):
                 hnn.BatchNorm1d(out_channels),
             )
 
+    compute_dtype = "fp32"     # stand-alone forward (ResNet1D_SE hands its own dtype to its blocks)
+
     def forward(self, x):
-        raise RuntimeError("BasicBlock1D is executed by ResNet1D_SE's fused launch plan; call the encoder")
+        """relu(se(bn2(conv2(relu(bn1(conv1 x))))) + identity) on the per-op kernels (ecgmm/hip/blocks.py): the values
+        the encoder's launch plan computes for this block, for inspection / feature extraction.  No autograd graph
+        (training goes through ``ResNet1D_SE.forward``); in train mode the BatchNorm running statistics update."""
+        from .hip import blocks
+        return blocks.basic_block1d_forward(self, x, self.compute_dtype)
 
 
 class ResNet1D_SE(nn.Module):
@@ -93,6 +102,8 @@ class ResNet1D_SE(nn.Module):
             hnn.Linear(64, num_classes),
         )
         self._spec = E.ResNet1DSpec()
+        for blk in (self.layer1, self.layer2, self.layer3):
+            blk.compute_dtype = compute_dtype
 
     def forward(self, x):
         spec = self._spec

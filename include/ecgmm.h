@@ -190,6 +190,11 @@ int ecgmm_stem_stats_rows(int N, int Cin, int H, int W, int R);
 int ecgmm_stem_pack(int dtype, const float* w_oihw, void* packed, int Cin, int R, void* stream);
 int ecgmm_stem_fwd(int dtype, const float* x, const void* packed, const float* bias, void* y, float* stats, int N,
                    int Cin, int H, int W, int R, void* stream);
+/* bf16 form of ecgmm_stem_fwd whose BatchNorm partial sums stay in registers across a workgroup's tiles: 4 rows per
+ * workgroup (ecgmm_stem_wg_stats_rows) instead of 4 per tile -- what the encoder plans call */
+int ecgmm_stem_wg_stats_rows(int N, int Cin, int H, int W, int R);
+int ecgmm_stem_fwd_wgrows(int dtype, const float* x, const void* packed, const float* bias, void* y, float* stats, int N,
+                          int Cin, int H, int W, int R, void* stream);
 size_t ecgmm_stem_bwd_weight_workspace(int N, int Cin, int H, int W, int R);
 int ecgmm_stem_bwd_weight(int dtype, const float* x, const void* dy, float* dw_oihw, int accumulate, void* ws,
                           size_t ws_bytes, int N, int Cin, int H, int W, int R, void* stream);

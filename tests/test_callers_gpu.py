@@ -73,3 +73,36 @@ def test_attribution_entry_point_and_kfold_harness(tmp_path):
     assert set(df.columns) >= {"Sample_ID", "Image_%", "Signal_%", "Clinical_%", "Label", "Class"} and len(df) == 16
     aucs = train_kfold.main(cfg, num_epochs=1, quiet=True)
     assert len(aucs) == 2 and all(np.isnan(a) or 0.0 <= a <= 1.0 for a in aucs)
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("cin,cout,stride,Ln", [(64, 64, 1, 96), (64, 128, 2, 101), (128, 256, 2, 64)])
+def test_block_level_modules_run_standalone(cin, cout, stride, Ln, training):
+    """``SEBlock.forward`` / ``BasicBlock1D.forward`` are ordinary callables in the reference
+    (multimodal_paper_modal_balance.py:58-62, 86-93); here they run on the per-op kernels (ecgmm/hip/blocks.py) and give
+    the oracle block's values (fp32 path, train mode = batch statistics + running-statistics update, eval mode = running
+    statistics)."""
+    from ecgmm.multimodal_paper_modal_balance import BasicBlock1D, SEBlock
+    ref = fill.hash_fill_module(O.BasicBlock1D(cin, cout, stride=stride), "blk.")
+    ref.bn1.running_var.mul_(1.7); ref.bn2.running_mean.add_(0.1)
+    blk = BasicBlock1D(cin, cout, stride=stride)
+    blk.load_state_dict(ref.state_dict())
+    blk = blk.to(DEV)
+    ref.train(training); blk.train(training)
+    x = fill.hash_tensor((5, cin, Ln), 77, 1.2)
+    with torch.no_grad():
+        want = ref(x)
+    got = blk(x.to(DEV))
+    assert got.shape == want.shape and not got.requires_grad
+    assert (got.cpu() - want).abs().max() < 2e-4, float((got.cpu() - want).abs().max())
+    if training:
+        for a, b in ((blk.bn1, ref.bn1), (blk.bn2, ref.bn2)):
+            assert torch.allclose(a.running_mean.cpu(), b.running_mean, atol=1e-5) and int(a.num_batches_tracked) == 1
+            assert torch.allclose(a.running_var.cpu(), b.running_var, rtol=1e-4, atol=1e-6)
+    se_ref = fill.hash_fill_module(O.SEBlock(cout), "se.")
+    se = SEBlock(cout); se.load_state_dict(se_ref.state_dict()); se = se.to(DEV)
+    with torch.no_grad():
+        w2 = se_ref(want)
+    assert (se(got).cpu() - w2).abs().max() < 2e-4
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        blk.cpu()(x)

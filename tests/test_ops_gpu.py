@@ -423,6 +423,15 @@ def test_stem_fwd_wgrad(case, dt):
     s = stats.sum(0).cpu()
     assert torch.allclose(s[0], y_ref.detach().sum(dim=(0, 2, 3)), rtol=1e-4, atol=2e-2)
 
+    if dt == L.BF16:   # per-workgroup statistics rows (what the plans call): same output bits, same column sums
+        rows2 = lib.ecgmm_stem_wg_stats_rows(N, Cin, H, W, R)
+        stats2 = torch.full((rows2 + 64, 2, 64), float("nan"), device=DEV)
+        yg2 = torch.empty_like(yg)
+        L.check(lib.ecgmm_stem_fwd_wgrows(dt, ptr(xg), ptr(pk), ptr(bg), ptr(yg2), ptr(stats2), N, Cin, H, W, R, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(yg2.view(torch.int16), yg.view(torch.int16))
+        s2 = stats2[:rows2].sum(0).cpu()
+        assert torch.allclose(s2, s, rtol=2e-5, atol=1e-5 * float(s.abs().max()) + 1e-3)
     dyg = to_nhwc(dy, dt)
     nb = lib.ecgmm_stem_bwd_weight_workspace(N, Cin, H, W, R)
     ws = torch.empty(nb, device=DEV, dtype=torch.uint8)

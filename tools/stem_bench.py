@@ -48,6 +48,10 @@ ws2 = torch.empty(nb2, device=dev, dtype=torch.uint8)
 scratch = torch.empty(lib.ecgmm_bn_bwd_scratch(1, N * OH * OW, 64), device=dev, dtype=torch.uint8)
 dgam, dbet = torch.empty(64, device=dev), torch.empty(64, device=dev)
 dy2 = torch.empty_like(dy)
+rows3 = lib.ecgmm_stem_wg_stats_rows(N, Cin, H, W, R)
+stats3 = torch.empty(rows3 + 64, 2, 64, device=dev)
+def fwd_wg():
+    L.check(lib.ecgmm_stem_fwd_wgrows(1, ptr(x), ptr(pk), None, ptr(y), ptr(stats3), N, Cin, H, W, R, stream()))
 def stats_only():
     L.check(lib.ecgmm_stem_stats_only(1, ptr(x), ptr(pk), None, ptr(stats2), N, Cin, H, W, R, stream()))
 def pool_fwd():
@@ -58,7 +62,7 @@ def pool_bn_bwd():
     L.check(lib.ecgmm_pool_bn_bwd(1, ptr(dp), ptr(pooled), ptr(idx), ptr(y), ptr(coef), ptr(gam), ptr(dgam), ptr(dbet), ptr(dy2), None, N, OH, OW, 64, ptr(scratch), stream()))
 def pool_bwd_fused():
     L.check(lib.ecgmm_stem_pool_bwd(ptr(x), ptr(pk), ptr(coef), ptr(gam), ptr(dp), ptr(pooled), ptr(idx), ptr(dgam), ptr(dbet), ptr(dw), ptr(ws2), nb2, N, Cin, H, W, stream()))
-for name, fn in (("stem_fwd", fwd), ("bnrelu_maxpool", maxpool), ("stem_stats_only", stats_only), ("stem_pool_fwd", pool_fwd),
+for name, fn in (("stem_fwd", fwd), ("stem_fwd (per-workgroup statistics rows)", fwd_wg), ("bnrelu_maxpool", maxpool), ("stem_stats_only", stats_only), ("stem_pool_fwd", pool_fwd),
                  ("pool_bn_bwd (reduce+finalize+apply)", pool_bn_bwd), ("stem_wgrad(+reduce)", wgrad),
                  ("stem_pool_bwd (reduce+finalize+fused wgrad+reduce)", pool_bwd_fused)):
     for _ in range(3):
