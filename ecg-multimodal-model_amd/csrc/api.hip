@@ -147,6 +147,18 @@ int ecgmm_conv_bwd_data_bnred(int dtype, const ecgmm_conv_desc* c, const void* d
   if (rc == 0 && e.red_done) *nrows = e.red_rows_n;
   return rc;
 }
+// ecgmm_conv_fwd whose BatchNorm partial sums come as ONE row per workgroup where the halo-resident kernel serves the shape
+// (*nrows rows of [2][Cout]; the per-64-pixel layout and its row count otherwise) -- the form the encoder plans use.
+int ecgmm_conv_fwd_wgrows(int dtype, const ecgmm_conv_desc* c, const void* x, const void* w_fwd, const float* bias, void* y,
+                          float* stats, int* nrows, int act, void* stream) {
+  if (!stats || !nrows) ECG_FAIL(ECGMM_ERR_SHAPE, "conv_fwd_wgrows: null statistics buffer / row count");
+  const ConvGeom g = geom_of(c);
+  ConvEpi e = {};
+  e.wg_rows = 1;
+  int rc = ecg_conv_igemm(dtype, 0, g, x, w_fwd, y, bias, nullptr, stats, act, S_(stream), &e);
+  *nrows = e.stats_rows > 0 ? e.stats_rows : ecg_conv_stats_rows((long)g.N * g.OH * g.OW);
+  return rc;
+}
 // Partial rows a launch of ecgmm_conv_bwd_data_bnred writes for this geometry (0 = the fused form does not apply): the
 // number an encoder plan uses when ANOTHER call consumes the rows (csrc/plan_resnet18.hip) -- follows ecgmm_conv_halo_cus.
 int ecgmm_conv_bwd_data_bnred_rows(int dtype, const ecgmm_conv_desc* c) {

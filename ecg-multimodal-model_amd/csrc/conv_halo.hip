@@ -398,6 +398,28 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 
   bf16_t* __restrict__ dst = (bf16_t*)p.dst;
   const bf16_t* __restrict__ addend = (const bf16_t*)p.addend;
+  // RACC (64-channel tiles, one row per workgroup): the per-channel sums stay in each lane's registers across ALL of the
+  // workgroup's tiles and go through the 16-lane DPP reduction once, at the end -- per tile that reduction was 8 (BN = 64:
+  // 16 values x 4 DPP adds x 2 + LDS read-modify-write) of a 64-channel tile's ~100 us (profiles/r02_halo_ablation.txt).
+  // The 128-channel instantiations have no registers to spare (they sit at 256 with scratch): per-tile LDS accumulation stays.
+  // (Forward only: with 16 more live registers the fused-reduction input gradient (MODE 1) spills 72 B per lane.)
+#ifdef HALO_NO_RACC   // A/B build (make halo_noracc): per-tile LDS accumulation everywhere
+  constexpr bool RACC = false;
+#else
+  constexpr bool RACC = BN == 64 && MODE == 0 && NW == 8;
+#endif
+  constexpr int TA_ = TC / 2;
+  float rs1[RACC && MODE == 0 ? TC : 1][4], rs2[RACC && MODE == 0 ? TC : 1][4];
+  float rq1[RACC && MODE == 1 ? TA_ : 1][8], rq2[RACC && MODE == 1 ? TA_ : 1][8];
+#pragma unroll
+  for (int a = 0; a < (RACC && MODE == 0 ? TC : 1); ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rs1[a][j] = rs2[a][j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < (RACC && MODE == 1 ? TA_ : 1); ++a)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rq1[a][j] = rq2[a][j] = 0.f;
+  const bool racc = RACC && p.wg_rows != 0;
   bool first_tile = true;
   for (;;) {
     set_baddr(m0);
@@ -625,7 +647,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
         // layout (what conv_igemm writes: forward only), or -- wg_rows -- added to this wave's LDS accumulators (only this
         // wave's fr == 0 lanes touch its [pixel quarter][channel] slots: plain read-modify-write, fixed order, reproducible)
         float* lrow = sacc + wp * 2 * BN + wc * C::CPW;
-        if (MODE == 0) {
+        if (RACC && racc) {
+          if constexpr (RACC && MODE == 0) {
+#pragma unroll
+            for (int a = 0; a < TC; ++a)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                rs1[a][j] += s1[a][j];
+                rs2[a][j] += s2[a][j];
+              }
+          }
+          if constexpr (RACC && MODE == 1) {
+#pragma unroll
+            for (int ap = 0; ap < TA; ++ap)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                rq1[ap][j] += q1[ap][j];
+                rq2[ap][j] += q2[ap][j];
+              }
+          }
+        } else if (MODE == 0) {
           float* srow = p.stats + (size_t)(mt_cur * 4 + wp) * 2 * p.Cd + cw + fq * 4;
 #pragma unroll
           for (int a = 0; a < TC; ++a) {
@@ -672,6 +713,44 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
       for (int b = 0; b < TP; ++b) asm volatile("" ::"v"(acc[a][b]));
 #endif
     if (!more) break;
+  }
+  if (RACC && racc && ((MODE == 0 && p.stats) || (MODE == 1 && p.red_y))) {
+    // the register sums of all tiles: one 16-lane DPP reduction, into this wave's (zero-filled) LDS slots
+    float* lrow = sacc + wp * 2 * BN + wc * C::CPW;
+    const int cl = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+    if constexpr (RACC && MODE == 0) {
+#pragma unroll
+      for (int a = 0; a < TC; ++a) {
+        f32x4 r1, r2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r1[j] = row16_sum(rs1[a][j]);
+          r2[j] = row16_sum(rs2[a][j]);
+        }
+        if (fr == 0) {
+          *reinterpret_cast<f32x4*>(lrow + a * 16 + fq * 4) = r1;
+          *reinterpret_cast<f32x4*>(lrow + BN + a * 16 + fq * 4) = r2;
+        }
+      }
+    }
+    if constexpr (RACC && MODE == 1) {
+#pragma unroll
+      for (int ap = 0; ap < TA_; ++ap) {
+        f32x4 r1[2], r2[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          r1[j >> 2][j & 3] = row16_sum(rq1[ap][j]);
+          r2[j >> 2][j & 3] = row16_sum(rq2[ap][j]);
+        }
+        if (fr == 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<f32x4*>(lrow + ap * 32 + cl + u * 4) = r1[u];
+            *reinterpret_cast<f32x4*>(lrow + BN + ap * 32 + cl + u * 4) = r2[u];
+          }
+        }
+      }
+    }
   }
   if (p.wg_rows && (p.stats || p.red_y)) {
     // one partial row per workgroup: the four pixel quarters' accumulators, summed in fixed order

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ecgmm_pack_conv_weight": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "ecgmm_conv_stats_rows": (i32, [i64]),
     "ecgmm_conv_fwd": (i32, [i32, P(ConvDesc), vp, vp, vp, vp, vp, i32, vp]),
+    "ecgmm_conv_fwd_wgrows": (i32, [i32, P(ConvDesc), vp, vp, vp, vp, vp, vp, i32, vp]),
     "ecgmm_conv_bwd_data": (i32, [i32, P(ConvDesc), vp, vp, vp, vp, vp]),
     "ecgmm_conv_bwd_weight_workspace": (sz, [i32, P(ConvDesc)]),
     "ecgmm_conv_bwd_weight": (i32, [i32, P(ConvDesc), vp, vp, vp, i32, vp, sz, vp]),

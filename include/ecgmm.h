@@ -176,6 +176,11 @@ int ecgmm_conv_halo_stagger(int on);
 int ecgmm_conv_wgrad_ring_enable(int on);
 int ecgmm_conv_fwd(int dtype, const ecgmm_conv_desc* c, const void* x, const void* w_fwd, const float* bias, void* y,
                    float* stats, int act, void* stream);
+/* the same with the BatchNorm partial sums as ONE row per workgroup where the halo-resident kernel serves the shape (*nrows
+ * rows of [2][Cout], at most 512; otherwise the per-64-pixel rows above and their count): what the encoder plans call.
+ * stats: room for ecgmm_conv_stats_rows(N*OH*OW) + ECGMM_BN_TAIL_ROWS rows. */
+int ecgmm_conv_fwd_wgrows(int dtype, const ecgmm_conv_desc* c, const void* x, const void* w_fwd, const float* bias, void* y,
+                          float* stats, int* nrows, int act, void* stream);
 /* autograd of the above: input gradient (addend, nullable, is added to dx) and weight gradient */
 int ecgmm_conv_bwd_data(int dtype, const ecgmm_conv_desc* c, const void* dy, const void* w_dgrad, const void* addend,
                         void* dx, void* stream);

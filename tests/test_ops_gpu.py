@@ -372,6 +372,37 @@ def test_finalize_folded_into_the_consumer_pass(dt, shape):
     assert rel_err(c[0], d[0]) < (1e-6 if dt == L.F32 else 2e-3)
 
 
+@pytest.mark.parametrize("case", [(64, 16, 16, 64, 64), (300, 8, 8, 64, 64), (16, 16, 16, 128, 128), (8, 1, 160, 128, 128)])
+def test_conv_forward_statistics_one_row_per_workgroup(case):
+    """ecgmm_conv_fwd_wgrows (the plans' form: partial sums accumulated per workgroup -- in registers across its tiles for the
+    64-channel tiles, in LDS for the 128-channel ones) == ecgmm_conv_fwd: identical output bits, same column sums."""
+    N, H, W, Cin, Cout = case
+    lib = L.lib()
+    dt = L.BF16
+    R = 3 if H > 1 else 1
+    d = conv_desc(N, H, W, Cin, Cout, R, 3, 1, R // 2, 1)
+    M = N * H * W
+    x = to_nhwc(bf16_round(fill.hash_tensor((N, Cin, H, W), 81)), dt)
+    wf, _ = pack_weight(bf16_round(fill.hash_tensor((Cout, Cin, R, 3), 82, 0.05)), dt)
+    rows = lib.ecgmm_conv_stats_rows(M)
+    try:
+        lib.ecgmm_conv_halo_enable(2)
+        y0 = torch.empty(M * Cout, device=DEV, dtype=torch.bfloat16)
+        s0 = torch.zeros(rows + 64, 2, Cout, device=DEV)
+        L.check(lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(wf), None, ptr(y0), ptr(s0), 0, stream()))
+        y1 = torch.empty_like(y0)
+        s1 = torch.full((rows + 64, 2, Cout), float("nan"), device=DEV)
+        n = C.c_int(0)
+        L.check(lib.ecgmm_conv_fwd_wgrows(dt, C.byref(d), ptr(x), ptr(wf), None, ptr(y1), ptr(s1), C.byref(n), 0, stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.ecgmm_conv_halo_enable(1)
+    assert 1 <= n.value <= 512 and torch.isfinite(s1[:n.value]).all()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    a, b = s0[:rows].sum(0), s1[:n.value].sum(0)
+    assert torch.allclose(a, b, rtol=2e-5, atol=1e-5 * float(a.abs().max()) + 1e-3), float((a - b).abs().max())
+
+
 def test_conv_rejects_bad_shapes():
     lib = L.lib()
     d = conv_desc(1, 8, 8, 6, 64, 3, 3, 1, 1, 1)   # Cin not a multiple of the 16-byte vector

@@ -17,6 +17,7 @@ ap.add_argument("--lib", default="", help="A/B: path of another build of libecgm
 ap.add_argument("--ring", type=int, default=-1, help="wgrad_ring_kernel: 0 off, 1 on (default)")
 ap.add_argument("--halo", type=int, default=-1, help="conv_halo.hip: 0 never, 1 where faster (default), 2 wherever applicable")
 ap.add_argument("--w4", type=int, default=-1, help="64->64 3x3 layers on 4-wave workgroups, two per CU: 0 off, 1 on (default)")
+ap.add_argument("--wgrows", action="store_true", help="forward statistics as one row per workgroup (the plans' form)")
 ap.add_argument("--stagger", type=int, default=-1, help="halo kernel: waves 4-7 one MFMA block late: 0 off, 1 on (default)")
 a = ap.parse_args()
 if a.lib:
@@ -58,8 +59,9 @@ for name, H, W, Cin, Cout, R, S, st, ph, pw in SHAPES:
     nb = lib.ecgmm_conv_bwd_weight_workspace(dt, C.byref(d))
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     flops = 2.0 * B * OH * OW * Cout * R * S * Cin
+    nrows = C.c_int(0)
     runs = {
-        "fwd": lambda: lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), None if a.no_stats else ptr(stats), 0, stream()),
+        "fwd": (lambda: lib.ecgmm_conv_fwd_wgrows(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(stats), C.byref(nrows), 0, stream())) if a.wgrows else lambda: lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), None if a.no_stats else ptr(stats), 0, stream()),
         "dgrad": lambda: lib.ecgmm_conv_bwd_data(dt, C.byref(d), ptr(dy), ptr(w), None, ptr(dx), stream()),
         "wgrad": lambda: lib.ecgmm_conv_bwd_weight(dt, C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), nb, stream()),
     }
