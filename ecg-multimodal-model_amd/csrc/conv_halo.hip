@@ -115,9 +115,16 @@ template <int BN, int NW = 8> struct HaloCfg {
 // loop, so the NEXT tile's halo is fetched there during this tile's K loop (through the same in-loop piece schedule
 // that otherwise fetches the next channel slice) instead of from the epilogue, where only ~0.6 us of work covered its
 // HBM latency: 1.5-2 us of exposed wait per tile, 12 tiles per workgroup on the 56x56 layers.
-template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8>
+// PP (round 3, the guide's 8-phase GEMM discipline applied to this loop): PING-PONG between the two waves of a SIMD.  A K step
+// becomes four phases -- read the k-step-0 fragments (+ issue the step's fills) | barrier | its 16 MFMAs | barrier | read the
+// k-step-1 fragments | barrier | its 16 MFMAs | barrier -- and waves 4-7 run ONE BARRIER behind waves 0-3 (an extra
+// s_barrier in front of their K loop, one behind the others'): in every interval one wave of each SIMD issues MFMAs while its
+// partner issues LDS reads / fills, instead of both meeting at the matrix pipe and then both at the LDS.  One fragment
+// register set instead of two.  Same products in the same order: results bit-identical to the lock-step form.
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(HaloParams p) {
   using C = HaloCfg<BN, NW>;
+  static_assert(!PP || (NW == 8 && !NCS1), "ping-pong: 8-wave workgroups");
   static_assert(!(NCS1 && NW == 4), "one halo buffer: the next tile's halo cannot stream in during the K loop");
   static_assert(NW == 8 || RS % 3 == 0, "3-slot ring: the slot of a step is its tap index mod 3");
   constexpr int HTHREADS = NW * 64;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
   // (64-channel tiles only -- measured stand-alone, batch 256: layer 1 forward 97.8 -> 91.2 us, input gradient 94.3 -> 88.9 us;
   // the 128-channel tiles of layers 2-4 got 3-5 % SLOWER with it (their two MFMA blocks per step already fill the interval,
   // and the branch cost them registers: 12 -> 52 B of scratch), so they stay in lock step)
-  const bool late = NW == 8 && BN == 64 && p.stagger != 0 && wv >= 4;
+  const bool late = !PP && NW == 8 && BN == 64 && p.stagger != 0 && wv >= 4;
   // weight ring slot of K step g (tap t): 4 slots -> g & 3; 3 slots -> t % 3 (every slice has RS = 3 or 9 steps)
   auto slot_of = [](int g, int t) -> int { return C::NWS == 4 ? (g & 3) : (t % 3); };
   auto hbuf_of = [](int q) -> unsigned { return C::NHB == 2 ? (unsigned)(q & 1) * C::HBUF : 0u; };
@@ -396,6 +403,69 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     ++qs;
   };
 
+  // ---- the ping-pong form of a slice (PP): see the kernel's header.  Hazards, with waves 4-7 one barrier behind:
+  //   fills of step s+1 (issued at step s-2)  are waited for in front of B3 of step s by every wave; the first read of that slot
+  //                                           is waves 0-3's phase 1 of step s+1, behind B4 (= waves 4-7's B3): everybody's landed;
+  //   the slot step s+3's fill overwrites      (step s-1's) was last read in phase 3 of step s-1, and those reads are complete
+  //                                           (lgkmcnt(0)) in front of that phase's barrier B3 -- waves 4-7's B3 of step s-1 is the
+  //                                           barrier waves 0-3 pass last (their B4) before phase 1 of step s issues the fill.
+  auto slice_pp = [&](int cs, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const unsigned hb = hbuf_of(qs), hbn = hbuf_of(qs + 1);
+#pragma unroll
+    for (int b = 0; b < TP; ++b)
+#pragma unroll
+      for (int t2 = 0; t2 < RSP; ++t2) asm volatile("" : "+v"(baddr[b][t2]));
+#pragma unroll
+    for (int t = 0; t < RS; ++t) {
+      const int s = g0 + t;
+      const auto n_halo = [](int tt, bool last) { return (!last && tt < RS - 1 && tt * HPS < C::NPW_MAX)
+                                                      ? ((tt + 1) * HPS < C::NPW_MAX ? HPS : C::NPW_MAX - tt * HPS) : 0; };
+      const auto n_fill = [&](int tt, bool last) {
+        return ((last && tt + D >= RS) ? 0 : C::WPS) + n_halo(tt, last) + ((last && tt == 0) ? 3 : 0);
+      };
+      const bool wrap = t + D >= RS;
+      // phase 1: k-step-0 fragments, then this step's fills
+      ld_a(fa0, slot_of(s, t), 0u);
+#pragma unroll
+      for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, t) + hb);
+      if (LAST && t == 0) prefetch_epilogue_operands();   // 3 DMAs, counted in n_fill
+      if (!(LAST && wrap)) dma_w(wrow, slot_of(s + D, (t + D) % RS), cs + (wrap ? 1 : 0), (t + D) % RS);
+      if (n_halo(t, LAST) > 0) dma_halo(hbn, cs + 1, t * HPS, (t + 1) * HPS);
+      __builtin_amdgcn_s_barrier();                       // B1
+      wait_lds();
+      // phase 2
+      mma(fa0, fb0);
+      __builtin_amdgcn_s_barrier();                       // B2
+      // phase 3: k-step-1 fragments; the fills of step s + 1 have landed (all but the last two steps' fills)
+      ld_a(fa0, slot_of(s, t), 64u);
+#pragma unroll
+      for (int b = 0; b < TP; ++b) fb0[b] = ld_b((bad(b, t) ^ 64u) + hb);
+      const int outstanding = (D == 3 ? (t == 0 ? n_fill(RS - 1, false) : n_fill(t - 1, LAST)) : 0) + n_fill(t, LAST);
+      if (outstanding == 0) wait_vmcnt<0>();
+      else if (outstanding == 1) wait_vmcnt<1>();
+      else if (outstanding == 2) wait_vmcnt<2>();
+      else if (outstanding == 3) wait_vmcnt<3>();
+      else if (outstanding == 4) wait_vmcnt<4>();
+      else if (outstanding == 5) wait_vmcnt<5>();
+      else if (outstanding == 6) wait_vmcnt<6>();
+      else if (outstanding == 7) wait_vmcnt<7>();
+      else if (outstanding == 8) wait_vmcnt<8>();
+      else if (outstanding == 9) wait_vmcnt<9>();
+      else if (outstanding == 10) wait_vmcnt<10>();
+      else if (outstanding == 11) wait_vmcnt<11>();
+      else if (outstanding == 12) wait_vmcnt<12>();
+      else wait_vmcnt<0>();
+      wait_lds();
+      __builtin_amdgcn_s_barrier();                       // B3
+      // phase 4
+      mma(fa0, fb0);
+      __builtin_amdgcn_s_barrier();                       // B4
+    }
+    g0 += RS;
+    ++qs;
+  };
+
   bf16_t* __restrict__ dst = (bf16_t*)p.dst;
   const bf16_t* __restrict__ addend = (const bf16_t*)p.addend;
   // RACC (64-channel tiles, one row per workgroup): the per-channel sums stay in each lane's registers across ALL of the
@@ -437,16 +507,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     first_tile = false;
     wait_lds();
     __builtin_amdgcn_s_barrier();
-    ld_a(fa0, slot_of(g0, 0), 0u);
-    {
-      const unsigned hb = hbuf_of(qs);
-#pragma unroll
-      for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, 0) + hb);
-    }
     using F_ = std::integral_constant<bool, false>;
     using T_ = std::integral_constant<bool, true>;
-    for (int cs = 0; cs + 1 < p.ncs; ++cs) slice(cs, F_{});
-    slice(p.ncs - 1, T_{});
+    if constexpr (PP) {
+      if (wv >= 4) __builtin_amdgcn_s_barrier();          // waves 4-7: one barrier behind, for the whole K loop
+      for (int cs = 0; cs + 1 < p.ncs; ++cs) slice_pp(cs, F_{});
+      slice_pp(p.ncs - 1, T_{});
+      if (wv < 4) __builtin_amdgcn_s_barrier();           // ... and level again: every LDS read of the tile is complete
+    } else {
+      ld_a(fa0, slot_of(g0, 0), 0u);
+      {
+        const unsigned hb = hbuf_of(qs);
+#pragma unroll
+        for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, 0) + hb);
+      }
+      for (int cs = 0; cs + 1 < p.ncs; ++cs) slice(cs, F_{});
+      slice(p.ncs - 1, T_{});
+    }
     // every wave is past the last step's barrier, i.e. has read its last fragments: the halo buffer and the weight
     // slots the next tile starts with are free; its fills are issued from inside this tile's epilogue (below)
     // the K loop ends HERE for every accumulator (hipcc otherwise sinks the last slice's MFMAs of the second pixel half
@@ -788,14 +865,14 @@ int halo_gk(int ntn, int ntm, int wg_per_cu = 1) {
   return Gk < 1 ? 1 : Gk;
 }
 
-template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8>
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false>
 int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   using C = HaloCfg<BN, NW>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS) != hipSuccess)
       ECG_FAIL(ECGMM_ERR_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", C::LDS);
     attr_set[dev] = true;
@@ -807,7 +884,7 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   // (4-wave workgroups: two per CU)
   const int Gk = halo_gk(q.ntn, q.ntm, NW == 4 ? 2 : 1);
   *rows_out = Gk;
-  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
   return 0;
 }
@@ -820,6 +897,7 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
 // compiler-inserted scratch traffic inside the counted-vmcnt K loop its partial rows were NOT reproducible run to run once
 // other streams shared the GPU (tools/det_check_mm.py; every scratch-free instantiation is bit-reproducible).
 int g_halo_w4 = -1;
+int g_halo_pp = -1;       // ping-pong K loop on the 128-channel tiles (-1: read ECGMM_HALO_PP, default on)
 int g_halo_stagger = -1;  // waves 4-7 staggered by one MFMA block (-1: read ECGMM_HALO_STAGGER, default on)
 int g_halo_enabled = -1;  // read once from ECGMM_CONV_HALO: 0 = off, 1 = where it is the faster kernel (default), 2 = wherever applicable
 
@@ -831,6 +909,10 @@ extern "C" int ecgmm_conv_halo_enable(int on) {
   return 0;
 }
 
+extern "C" int ecgmm_conv_halo_pingpong(int on) {
+  g_halo_pp = on != 0;
+  return 0;
+}
 extern "C" int ecgmm_conv_halo_stagger(int on) {
   g_halo_stagger = on != 0;
   return 0;
@@ -902,6 +984,7 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
     }
   }
   if (g_halo_stagger < 0) { const char* e = getenv("ECGMM_HALO_STAGGER"); g_halo_stagger = !(e && e[0] == '0'); }
+  if (g_halo_pp < 0) { const char* e = getenv("ECGMM_HALO_PP"); g_halo_pp = !(e && e[0] == '0'); }
   p.stagger = g_halo_stagger;
   int wg = 0;
   const bool wide = p.Cd > 64;
@@ -917,6 +1000,13 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
     if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
     else if (p.red_y) rc = launch_halo<64, 9, 1, true>(p, &wg, stream);
     else rc = launch_halo<64, 9, 2, true>(p, &wg, stream);
+  } else if (wide && g.R == 3 && g_halo_pp) {
+    // 128-channel 3x3 tiles: ping-pong K loop.  Same-call A/B against the lock-step loop (tools/conv_bench.py --pp, batch 256):
+    // layer 2 fwd 79-82 -> 74 us, dgrad 75-82 -> 70-75; layer 3 64.5-65.7 -> 62.5 / 62.4-63.2 -> 60.0; layer 4 58.3 -> 55-56 /
+    // 56.3 -> 52.7-53.7 (-4...-10 %).  The 1x3 layers of the signal encoder (3 steps per slice) measured 2 % slower: lock step.
+    if (mode == 0) rc = launch_halo<128, 9, 0, false, 8, true>(p, &wg, stream);
+    else if (p.red_y) rc = launch_halo<128, 9, 1, false, 8, true>(p, &wg, stream);
+    else rc = launch_halo<128, 9, 2, false, 8, true>(p, &wg, stream);
   } else if (g.R == 3) {
     if (mode == 0) rc = wide ? launch_halo<128, 9, 0>(p, &wg, stream) : launch_halo<64, 9, 0>(p, &wg, stream);
     else if (p.red_y) rc = wide ? launch_halo<128, 9, 1>(p, &wg, stream) : launch_halo<64, 9, 1>(p, &wg, stream);

@@ -170,6 +170,10 @@ int ecgmm_conv_halo_w4(int on);
  * in front of it, so the two waves of a SIMD alternate between the matrix pipe and the LDS / fill issue instead of meeting
  * there: 1 = on (default), 0 = lock step.  Pure scheduling (bit-identical results).  Start-up value: ECGMM_HALO_STAGGER. */
 int ecgmm_conv_halo_stagger(int on);
+/* Halo conv kernel, 128-channel tiles: ping-pong K loop (each K step as four read | MFMA phases, waves 4-7 one barrier behind
+ * waves 0-3, so one wave of every SIMD feeds the matrix pipe while its partner reads LDS / issues fills): 1 = on (default),
+ * 0 = the lock-step loop.  Bit-identical results.  Start-up value: ECGMM_HALO_PP. */
+int ecgmm_conv_halo_pingpong(int on);
 /* Weight gradients of the same stride-1 3x3 / 1x3 bf16 convolutions keep their x operand in an LDS ring of pixel rows
  * (wgrad_ring_kernel, csrc/conv_wgrad.hip) instead of one gathered tile per filter tap: 0 = never, 1 = for the shapes
  * it is faster on (default), 2 = wherever applicable (A/B, tests).  Start-up value: ECGMM_WGRAD_RING=0|1|2. */
