@@ -376,6 +376,7 @@ struct WgradRingParams {
   int steps_per_split;
   int HL, HLa;           // halo pixels (pad_h * W + 1) and the same rounded up to a multiple of 8
   unsigned mul_hw, sh_hw, mul_w, sh_w;
+  int pingpong;          // two-group workgroups, 9 taps: the groups run half a K step apart (see the K loop)
 };
 
 constexpr int RING_ROWS = 256;
@@ -429,6 +430,15 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
   const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
   unsigned char* const smem = smem_wg + grp * RING_LDS;
   constexpr int TA = 4;   // wave layout as in wgrad_kernel: all 64 output channels x the wave's own 16 input channels
+  // PING-PONG between the two groups (round 3; the two waves of a SIMD are wave w of group 0 and wave w of group 1).  In lock
+  // step both groups run a K step's head (fill issue, the dy fragments, 18 tap addresses: no MFMA) together and then
+  // contend for the matrix pipe with 36 MFMAs each.  A second workgroup barrier in the middle of the step (behind the MFMAs
+  // of tap PP_SPLIT - 1) and ONE barrier of offset between the groups (an extra s_barrier in front of group 1's loop, one
+  // behind group 0's) make every interval pair one group's head + first MFMAs with the other group's MFMA-only second half.
+  // The groups share no LDS (own ring, own dy stages): every hazard is inside a group, whose waves stay in the same phase.
+  constexpr bool PP_OK = GROUPS == 2 && NT == 9;
+  constexpr int PP_SPLIT = 4;
+  const bool pp = PP_OK && p.pingpong != 0;
   const int ci_tiles = p.Cin / 64;
   int tile_id = blockIdx.x, split = blockIdx.y;
   if ((gridDim.y & 7) == 0 && gridDim.x > 1) {   // a split's tiles on one XCD (see wgrad_kernel)
@@ -566,6 +576,11 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
       for (int a = 0; a < TA; ++a)
         acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
                                                             __builtin_bit_cast(bf16x8_t, cur), acc[t][a], 0, 0, 0);
+      if (PP_OK && t == PP_SPLIT - 1 && pp) {   // the ping-pong's mid-step barrier (the K loop below)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // next step: 32 pixels on
     st_ow += d_ow;
@@ -588,6 +603,7 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the zero row's ds_write
     __builtin_amdgcn_s_barrier();
     unsigned rot = 0u;
+    if (pp && grp == 1) __builtin_amdgcn_s_barrier();   // group 1: one barrier (= half a step) behind, for the whole loop
     for (int k = 0; k < iters; ++k) {
       if (GROUPS == 1 || k < nsteps) {
         // fills RING_D steps ahead: dy stage (k + RING_D) & 3 was read in step k - 1 (every wave is past its barrier); the
@@ -601,10 +617,13 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
         if (younger >= 2) ring_wait_vmcnt<4>();
         else if (younger == 1) ring_wait_vmcnt<2>();
         else ring_wait_vmcnt<0>();
+      } else if (pp) {
+        __builtin_amdgcn_s_barrier();       // (a group that has run out of steps keeps the barrier count: the mid-step one)
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
     }
+    if (pp && grp == 0) __builtin_amdgcn_s_barrier();   // level again
   }
 
   if constexpr (GROUPS == 2) {   // group 1 -> LDS -> group 0 (see wgrad_kernel)
@@ -779,6 +798,14 @@ int pick_nsplit(const ConvGeom& g, int kp, int groups) {
 
 }  // namespace
 
+// Ping-pong between the two wave groups of wgrad_ring_kernel<9, 2> (see its K loop): 1 = on, 0 = lock step (DEFAULT: measured
+// stand-alone at batch 256, layers 1-4: 86.2 / 85.3 / 81.4 / 90.6 us in lock step, 86.6 / 86.7 / 82.4 / 91.8 us with it -- this
+// kernel's K step is not limited by the two groups meeting at the matrix pipe).  Start-up value: ECGMM_WGRAD_PP.  Bit-identical results.
+static int g_wgrad_pp = -1;
+extern "C" int ecgmm_conv_wgrad_pingpong(int on) {
+  g_wgrad_pp = on != 0;
+  return 0;
+}
 // Runtime switch (same-process A/B, tools/conv_bench.py --ring): 0 = every weight gradient on wgrad_kernel.
 extern "C" int ecgmm_conv_wgrad_ring_enable(int on) {
   g_wgrad_ring = on < 0 ? 0 : on > 2 ? 2 : on;
@@ -831,6 +858,8 @@ int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, 
     q.HL = g.pad_h * g.W + 1;
     q.HLa = (q.HL + 7) / 8 * 8;
     q.mul_hw = p.mul_hw; q.sh_hw = p.sh_hw; q.mul_w = p.mul_w; q.sh_w = p.sh_w;
+    if (g_wgrad_pp < 0) { const char* e = getenv("ECGMM_WGRAD_PP"); g_wgrad_pp = (e && e[0] == '1'); }
+    q.pingpong = g_wgrad_pp;
     dim3 grid((g.Cout / 64) * (g.Cin / 64), ns);
     if (groups == 2) rc = g.R == 3 ? launch_wgrad_ring<9, 2>(q, grid, stream) : launch_wgrad_ring<3, 2>(q, grid, stream);
     else rc = g.R == 3 ? launch_wgrad_ring<9, 1>(q, grid, stream) : launch_wgrad_ring<3, 1>(q, grid, stream);

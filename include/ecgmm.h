@@ -174,6 +174,11 @@ int ecgmm_conv_halo_stagger(int on);
  * waves 0-3, so one wave of every SIMD feeds the matrix pipe while its partner reads LDS / issues fills): 1 = on (default),
  * 0 = the lock-step loop.  Bit-identical results.  Start-up value: ECGMM_HALO_PP. */
 int ecgmm_conv_halo_pingpong(int on);
+/* Ring weight-gradient kernel (3x3, two 4-wave groups per workgroup): the groups run half a K step apart (a second barrier
+ * in the middle of the step, one barrier of offset), so one group's MFMA-only half pairs with the other's fill issue /
+ * fragment-address head: 1 = on, 0 = lock step (default: measured 1 % slower with it).  Bit-identical results.
+ * Start-up value: ECGMM_WGRAD_PP. */
+int ecgmm_conv_wgrad_pingpong(int on);
 /* Weight gradients of the same stride-1 3x3 / 1x3 bf16 convolutions keep their x operand in an LDS ring of pixel rows
  * (wgrad_ring_kernel, csrc/conv_wgrad.hip) instead of one gathered tile per filter tap: 0 = never, 1 = for the shapes
  * it is faster on (default), 2 = wherever applicable (A/B, tests).  Start-up value: ECGMM_WGRAD_RING=0|1|2. */

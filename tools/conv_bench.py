@@ -19,6 +19,7 @@ ap.add_argument("--halo", type=int, default=-1, help="conv_halo.hip: 0 never, 1 
 ap.add_argument("--w4", type=int, default=-1, help="64->64 3x3 layers on 4-wave workgroups, two per CU: 0 off, 1 on (default)")
 ap.add_argument("--wgrows", action="store_true", help="forward statistics as one row per workgroup (the plans' form)")
 ap.add_argument("--pp", type=int, default=-1, help="halo kernel, 128-channel tiles: ping-pong K loop 0 off, 1 on (default)")
+ap.add_argument("--wpp", type=int, default=-1, help="wgrad ring kernel: ping-pong between its two wave groups 0 off, 1 on (default)")
 ap.add_argument("--stagger", type=int, default=-1, help="halo kernel: waves 4-7 one MFMA block late: 0 off, 1 on (default)")
 a = ap.parse_args()
 if a.lib:
@@ -38,6 +39,8 @@ if a.halo >= 0:
     lib.ecgmm_conv_halo_enable(a.halo)
 if a.pp >= 0:
     lib.ecgmm_conv_halo_pingpong(a.pp)
+if a.wpp >= 0:
+    lib.ecgmm_conv_wgrad_pingpong(a.wpp)
 if a.stagger >= 0:
     lib.ecgmm_conv_halo_stagger(a.stagger)
 if a.w4 >= 0:
