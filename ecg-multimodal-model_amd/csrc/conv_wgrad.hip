@@ -518,6 +518,27 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
   }
   const int d_r = 32 % HW, d_oh = d_r / p.W, d_ow = d_r - d_oh * p.W;
 
+  // tap addresses of a step: per tap the ring byte the lane's lo / hi source pixel sits at (or the zero row when the tap
+  // leaves the image) -- pure VALU, no LDS / fill dependency.  SOFTWARE-PIPELINED one step ahead (round 3): the addresses of
+  // step k + 1 are computed inside step k's tap loop, two taps' worth behind each tap's MFMAs, where the VALU work runs
+  // under the matrix pipe; in front of the step's first MFMA it was ~100 VALU per wave that both groups executed at the
+  // same time with the pipe idle (ablation, layer 2: the kernel without its MFMAs took 57 of 85 us -- the MFMA time sat
+  // entirely on top of the rest).
+  unsigned al[NT], ah[NT];
+  auto tap_addr = [&](int t, int oh_l, int ow_l, unsigned rot_, unsigned& a_lo, unsigned& a_hi) {
+    int oh_h = oh_l, ow_h = ow_l + 4;
+    if (ow_h >= p.W) { ow_h -= p.W; ++oh_h; }
+    if (oh_h >= p.H) oh_h -= p.H;
+    const int r = t / 3, sx = t - r * 3;
+    const bool vl = ((unsigned)(oh_l + r - p.pad_h) < (unsigned)p.H) & ((unsigned)(ow_l + sx - 1) < (unsigned)p.W);
+    const bool vh = ((unsigned)(oh_h + r - p.pad_h) < (unsigned)p.H) & ((unsigned)(ow_h + sx - 1) < (unsigned)p.W);
+    const unsigned zrow = (unsigned)RING_ZERO + (unsigned)(8 * (pq & 1));
+    a_lo = vl ? ((A_lo[t] + rot_) & (RING_BYTES - 1)) : zrow;
+    a_hi = vh ? ((A_hi[t] + rot_) & (RING_BYTES - 1)) : zrow;
+  };
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tap_addr(t, st_oh, st_ow, 0u, al[t], ah[t]);   // the first step's
+
   auto compute = [&](int stage, unsigned rot) {
     const unsigned char* dyt = smem + RING_DY + stage * 4096;
     // dy fragments (A operand): the step's own tile, rows 8 fq + q (+ 4), as in wgrad_kernel
@@ -533,33 +554,21 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
       uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
       fa[a] = (u32x4){l2.x, l2.y, h2.x, h2.y};
     }
-    // border flags of the lane's two pixels
-    int oh_h = st_oh, ow_h = st_ow + 4;
-    if (ow_h >= p.W) { ow_h -= p.W; ++oh_h; }
-    if (oh_h >= p.H) oh_h -= p.H;
-    bool hl_[R], hh_[R], wl_[3], wh_[3];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      hl_[r] = (unsigned)(st_oh + r - p.pad_h) < (unsigned)p.H;
-      hh_[r] = (unsigned)(oh_h + r - p.pad_h) < (unsigned)p.H;
-    }
-#pragma unroll
-    for (int sx = 0; sx < 3; ++sx) {
-      wl_[sx] = (unsigned)(st_ow + sx - 1) < (unsigned)p.W;
-      wh_[sx] = (unsigned)(ow_h + sx - 1) < (unsigned)p.W;
-    }
-    const unsigned zrow = (unsigned)RING_ZERO + (unsigned)(8 * (pq & 1));
-    // all tap addresses first (VALU only), then the fragment reads software-pipelined ONE TAP AHEAD of the MFMAs that
-    // consume them: with the reads of tap t issued right in front of its MFMAs a wave waited out the LDS latency nine
-    // times per step (the kernel ran at ~30 % MFMA-busy whatever its fill scheme)
-    unsigned al[NT], ah[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int r = t / 3, sx = t - r * 3;
-      al[t] = (hl_[r] && wl_[sx]) ? ((A_lo[t] + rot) & (RING_BYTES - 1)) : zrow;
-      ah[t] = (hh_[r] && wh_[sx]) ? ((A_hi[t] + rot) & (RING_BYTES - 1)) : zrow;
-    }
+    // next step: 32 pixels on
+    int n_ow = st_ow + d_ow;
+    const bool cw = n_ow >= p.W;
+    n_ow -= cw ? p.W : 0;
+    int n_oh = st_oh + d_oh + (cw ? 1 : 0);
+    if (n_oh >= p.H) n_oh -= p.H;
+    const unsigned n_rot = (rot + 4096u) & (RING_BYTES - 1);
+    (void)rot;
+    // the fragment reads run ONE TAP AHEAD of the MFMAs that consume them: with the reads of tap t issued right in front of
+    // its MFMAs a wave waited out the LDS latency nine times per step (the kernel ran at ~30 % MFMA-busy whatever its fill scheme)
     auto rd_tap = [&](int t, u32x4& fb) {
+#if defined(WG_ABL) && WG_ABL == 2   // diagnostic: no x-tap fragment reads (operands = address bits)
+      fb = (u32x4){al[t], ah[t], 0x3c003c00u, 0x3c003c00u};
+      return;
+#endif
       s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + al[t]));
       s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + ah[t]));
       uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -572,22 +581,25 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
       u32x4& cur = (t & 1) ? fbB : fbA;
       u32x4& nxt = (t & 1) ? fbA : fbB;
       if (t + 1 < NT) rd_tap(t + 1, nxt);
+#if defined(WG_ABL) && WG_ABL == 1   // diagnostic: no MFMAs (fragments kept alive)
+      asm volatile("" ::"v"(cur), "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]));
+#else
 #pragma unroll
       for (int a = 0; a < TA; ++a)
         acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
                                                             __builtin_bit_cast(bf16x8_t, cur), acc[t][a], 0, 0, 0);
+#endif
+      // (tap t's addresses were consumed by rd_tap(t) one iteration ago: replace them by the next step's, under these MFMAs)
+      if (t >= 1) tap_addr(t - 1, n_oh, n_ow, n_rot, al[t - 1], ah[t - 1]);
       if (PP_OK && t == PP_SPLIT - 1 && pp) {   // the ping-pong's mid-step barrier (the K loop below)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // next step: 32 pixels on
-    st_ow += d_ow;
-    const bool cw = st_ow >= p.W;
-    st_ow -= cw ? p.W : 0;
-    st_oh += d_oh + (cw ? 1 : 0);
-    if (st_oh >= p.H) st_oh -= p.H;
+    tap_addr(NT - 1, n_oh, n_ow, n_rot, al[NT - 1], ah[NT - 1]);
+    st_oh = n_oh;
+    st_ow = n_ow;
   };
 
   const int nsteps = max(s_end - s_begin, 0);
@@ -608,7 +620,9 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
       if (GROUPS == 1 || k < nsteps) {
         // fills RING_D steps ahead: dy stage (k + RING_D) & 3 was read in step k - 1 (every wave is past its barrier); the
         // ring slots they overwrite hold pixels 256 rows back, behind this step's window (host: HL + HLa + 32 RING_D + 32 <= 256)
+#if !(defined(WG_ABL) && WG_ABL == 3)   // diagnostic 3: no fills inside the K loop
         if (k + RING_D < nsteps) dma_step((k + RING_D) % RING_NDY, s_begin + k + RING_D);
+#endif
         compute(k % RING_NDY, rot);
         rot = (rot + 4096u) & (RING_BYTES - 1);
         // step k + 1's fills have landed: all but the groups of the steps after it (2 DMAs each) -- this wave's, then
