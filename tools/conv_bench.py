@@ -66,9 +66,14 @@ for name, H, W, Cin, Cout, R, S, st, ph, pw in SHAPES:
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     flops = 2.0 * B * OH * OW * Cout * R * S * Cin
     nrows = C.c_int(0)
+    ybn = torch.randn(B * H * W * Cin, device=dev).to(tdt)          # (fused BatchNorm-backward reduction: y of the consumer BN / a residual addend)
+    coefbn = torch.rand(4 * Cin, device=dev) + 0.5
+    rowsbn = torch.empty(512 * 2 * Cin, device=dev)
     runs = {
         "fwd": (lambda: lib.ecgmm_conv_fwd_wgrows(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(stats), C.byref(nrows), 0, stream())) if a.wgrows else lambda: lib.ecgmm_conv_fwd(dt, C.byref(d), ptr(x), ptr(w), None, ptr(y), None if a.no_stats else ptr(stats), 0, stream()),
         "dgrad": lambda: lib.ecgmm_conv_bwd_data(dt, C.byref(d), ptr(dy), ptr(w), None, ptr(dx), stream()),
+        "dgradred": lambda: lib.ecgmm_conv_bwd_data_bnred(dt, C.byref(d), ptr(dy), ptr(w), None, ptr(dx), ptr(ybn), ptr(ybn), ptr(coefbn), ptr(rowsbn), C.byref(nrows), stream()),
+        "dgradadd": lambda: lib.ecgmm_conv_bwd_data(dt, C.byref(d), ptr(dy), ptr(w), ptr(ybn), ptr(dx), stream()),
         "wgrad": lambda: lib.ecgmm_conv_bwd_weight(dt, C.byref(d), ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), nb, stream()),
     }
     line = f"{name:10s}"
