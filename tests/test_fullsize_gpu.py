@@ -124,3 +124,41 @@ def test_conv_kernels_are_linear_at_full_size():
     assert torch.allclose(stats[:rows, 0].sum(0), col.sum(0), rtol=2e-3, atol=20.0)
     assert torch.allclose(stats[:rows, 1].sum(0), (col * col).sum(0), rtol=5e-3)
 
+
+
+def test_pingpong_conv_loop_is_race_free_under_concurrent_load():
+    """The ping-pong K loop of the 128-channel 3x3 tiles (conv_halo_kernel<..., PP>: waves 4-7 one barrier behind waves 0-3,
+    LDS-DMA fills retired by counted vmcnt) is a synchronisation structure of its own: screen it for timing-dependent races.
+    Layers 2-4 at batch 256, forward and input gradient, 12 launches each while another stream streams 1 GB copies through the
+    chip: every launch must reproduce the lock-step kernel's output bit for bit."""
+    lib = L.lib()
+    side = torch.cuda.Stream()
+    big_a = torch.empty(256 << 20, device=DEV, dtype=torch.uint8)
+    big_b = torch.empty_like(big_a)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    try:
+        for (H, W, Cn) in ((28, 28, 128), (14, 14, 256), (7, 7, 512)):
+            d = L.ConvDesc(B, H, W, Cn, Cn, 3, 3, 1, 1, 1)
+            n = B * H * W * Cn
+            x = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16)
+            w = (torch.randn(Cn * Cn * 9, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+            for fn in (lib.ecgmm_conv_fwd, lib.ecgmm_conv_bwd_data):
+                def run(pp):
+                    lib.ecgmm_conv_halo_pingpong(pp)
+                    y = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+                    if fn is lib.ecgmm_conv_fwd:
+                        L.check(fn(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y), None, 0, stream()))
+                    else:
+                        L.check(fn(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y), stream()))
+                    return y
+                ref = run(0)
+                torch.cuda.synchronize()
+                for it in range(12):
+                    with torch.cuda.stream(side):
+                        big_b.copy_(big_a, non_blocking=True)
+                        big_a.copy_(big_b, non_blocking=True)
+                    y = run(1)
+                    torch.cuda.synchronize()
+                    assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), (H, Cn, fn.__name__, it)
+    finally:
+        lib.ecgmm_conv_halo_pingpong(1)
