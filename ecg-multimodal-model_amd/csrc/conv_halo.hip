@@ -55,6 +55,7 @@ struct HaloParams {
   int ntm;    // pixel tiles (M / 256)
   int ntn;    // channel tiles (Cd / BN); gridDim.x is a multiple of it
   int stagger;  // 1: waves 4-7 run their first MFMA block of a step AFTER the step's barrier (see slice())
+  unsigned mul_hw, sh_hw, mul_w, sh_w;   // exact division of a pixel index by H*W and by W: q = (x * mul) >> sh (x < 2^31)
 };
 
 __device__ __forceinline__ void hdma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_wave_base, unsigned voffset,
@@ -206,8 +207,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     for (int b = 0; b < TP; ++b) {
       const int pl = wp * 64 + b * 16 + fr;
       const int q = m0 + pl;
-      const int n = q / HW, rem = q - n * HW;
-      const int h = rem / p.W, w = rem - h * p.W;
+      // (magic-number division: the two runtime-divisor divisions per pixel tile were ~60 VALU each, four times per tile)
+      const int n = (int)(((unsigned long long)(unsigned)q * p.mul_hw) >> p.sh_hw), rem = q - n * HW;
+      const int h = (int)(((unsigned long long)(unsigned)rem * p.mul_w) >> p.sh_w), w = rem - h * p.W;
       bool okh[3], okw[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -845,6 +847,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 // workgroup per CU -- of at most ECGMM_HALO_CUS CUs -- shared out over the ntn channel tiles, never more than the pixel
 // tiles.  The ONE place this is computed: the launch and ecg_conv_halo_rows() (whose caller sizes the read of a row
 // buffer another launch fills) must agree for every setting of the cap.
+// exact unsigned division by d for dividends < 2^31: q = (x * m) >> sh
+void halo_magic_div(unsigned d, unsigned& m, unsigned& sh) {
+  int l = 0;
+  while ((1u << l) < d) ++l;
+  m = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  sh = 31 + l;
+}
 int g_halo_cu_cap = -1;  // -1: read ECGMM_HALO_CUS at first use; <= 0 after that: no cap
 int halo_gk(int ntn, int ntm, int wg_per_cu = 1) {
   static int ncu[16] = {0};
@@ -974,6 +983,8 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
   p.ncs = p.Cs / 64;
   p.HL = g.pad_h * g.W + g.pad_w;
   p.hrows = 256 + 2 * p.HL;
+  halo_magic_div((unsigned)(g.H * g.W), p.mul_hw, p.sh_hw);
+  halo_magic_div((unsigned)g.W, p.mul_w, p.sh_w);
   if (epi) {
     p.wg_rows = epi->wg_rows;
     if (epi->red_y) {
