@@ -59,6 +59,10 @@ struct IgemmParams {
   // "tap" of parity class (0,0) (a 3x3 pad-1 class (0,0) holds the centre tap only: both read source pixel (h/2, w/2))
   const void* src2;
   const void* wpk2;
+  // exact division of a (class-local) pixel index by Hc*Wc and by Wc: q = (x * mul) >> sh for x < 2^31, one set per
+  // output-pixel parity class (index blockIdx.z; index 0 when the launch has no classes).  A workgroup decodes 4 + TP pixels
+  // with two divisions each; with runtime divisors that was ~500 VALU in front of K loops of 2-8 stages (stride-2 dgrad).
+  unsigned mul_hw[4], sh_hw[4], mul_w[4], sh_w[4];
 };
 
 #ifdef ECG_STAMP
@@ -130,7 +134,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     if (m0 >= Mc) return;  // block-uniform
   }
   const int HWd = Hc * Wc;
-  const int n_first = m0 / HWd;
+  const int cls = PAR ? (int)blockIdx.z : 0;
+  const unsigned mhw = p.mul_hw[cls], shw = p.sh_hw[cls], mw = p.mul_w[cls], sw_ = p.sh_w[cls];
+  auto div_hw = [&](int x) -> int { return (int)(((unsigned long long)(unsigned)x * mhw) >> shw); };
+  auto div_w = [&](int x) -> int { return (int)(((unsigned long long)(unsigned)x * mw) >> sw_); };
+  const int n_first = div_hw(m0);
   const size_t img_elems = (size_t)p.Hs * p.Ws * p.Cs;
   const size_t left = ((size_t)p.Nimg - n_first) * img_elems * sizeof(T);
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(
@@ -149,9 +157,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     int pix = m0 + wave * 32 + i * 8 + lrow8;
     bool rok = pix < Mc;
     int pp = rok ? pix : m0;
-    int n = pp / HWd;
+    int n = div_hw(pp);
     int rem = pp - n * HWd;
-    int hd = rem / Wc, wd = rem - hd * Wc;
+    int hd = div_w(rem), wd = rem - hd * Wc;
     if (PAR) {
       hd = hd * 2 + ph;
       wd = wd * 2 + pw;
@@ -317,8 +325,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       for (int b = 0; b < TP; ++b) {
         int pix = m0 + wp * 64 + b * 16 + fr;
         if (PAR) {
-          const int n = pix / HWd, rem = pix - n * HWd;
-          const int h2 = rem / Wc, w2 = rem - h2 * Wc;
+          const int n = div_hw(pix), rem = pix - n * HWd;
+          const int h2 = div_w(rem), w2 = rem - h2 * Wc;
           pix = (n * p.Hd + h2 * 2 + ph) * p.Wd + w2 * 2 + pw;
         }
         prow[b] = (size_t)pix * p.Cd + n0 + wc * (BN / 2);
@@ -424,9 +432,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
       const bool pok = pix < Mc;
       if (PAR) {  // class-local index -> destination pixel
         int pp = pok ? pix : m0;
-        int n = pp / HWd;
+        int n = div_hw(pp);
         int rem = pp - n * HWd;
-        int h2 = rem / Wc, w2 = rem - h2 * Wc;
+        int h2 = div_w(rem), w2 = rem - h2 * Wc;
         pix = (n * p.Hd + h2 * 2 + ph) * p.Wd + w2 * 2 + pw;
       }
       float v[4];
@@ -601,6 +609,22 @@ int ecg_conv_igemm(int dtype, int mode, const ConvGeom& g, const void* src, cons
   }
   long M = (long)g.N * p.Hd * p.Wd;
   if (M <= 0 || M > 0x7fffffffL) ECG_FAIL(ECGMM_ERR_SHAPE, "conv: pixel count %ld out of range", M);
+  {
+    auto magic = [](unsigned d, unsigned& m, unsigned& sh) {   // exact for dividends < 2^31
+      if (d < 1) d = 1;
+      int l = 0;
+      while ((1u << l) < d) ++l;
+      m = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+      sh = 31 + l;
+    };
+    const bool par = mode == 1 && g.stride == 2;
+    for (int c = 0; c < 4; ++c) {
+      const int ph_ = par ? c >> 1 : 0, pw_ = par ? c & 1 : 0;
+      const int Hc_ = par ? (p.Hd - ph_ + 1) >> 1 : p.Hd, Wc_ = par ? (p.Wd - pw_ + 1) >> 1 : p.Wd;
+      magic((unsigned)(Hc_ * Wc_), p.mul_hw[c], p.sh_hw[c]);
+      magic((unsigned)Wc_, p.mul_w[c], p.sh_w[c]);
+    }
+  }
   p.M = (int)M;
   const int vec = dtype == ECGMM_BF16 ? 8 : 4;
   if (p.Cs % vec != 0) ECG_FAIL(ECGMM_ERR_SHAPE, "conv: reduction channels %d not a multiple of %d", p.Cs, vec);
