@@ -10,6 +10,19 @@ namespace {
 constexpr int EW_THREADS = 256;
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+// row -> sample by a magic-number multiply (rows < 2^31): the plain `r / rows_per_sample` on a 64-bit row index is a
+// ~100-instruction software division, once or twice per row in the gated passes of the signal encoder
+struct RowDiv { unsigned mul, sh; };
+__device__ __forceinline__ long row_div(long r, RowDiv d) { return (long)(((unsigned long long)(unsigned)r * d.mul) >> d.sh); }
+static RowDiv make_row_div(int d) {
+  unsigned dd = d < 1 ? 1u : (unsigned)d;
+  int l = 0;
+  while ((1u << l) < dd) ++l;
+  RowDiv r;
+  r.mul = (unsigned)(((1ull << (31 + l)) + dd - 1) / dd);
+  r.sh = 31u + (unsigned)l;
+  return r;
+}
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,6 +306,7 @@ struct BnActParams {
   long M;
   int C, rows_per_sample, relu;
   BnFin fin;               // fin.partial != null: the coefficients are folded from the producer's partial rows here
+  RowDiv rdiv;             // rows_per_sample as a magic multiplier
 };
 
 #ifndef BN_ACT_THREADS
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(BN_ACT_THREADS) void bn_act_kernel(BnActParams p) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) f[j] = f[j] * sc[j] + sh[j];
       if (p.gate) {
-        const float* gp = p.gate + (rr / p.rows_per_sample) * p.C + c0;
+        const float* gp = p.gate + row_div(rr, p.rdiv) * p.C + c0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) f[j] *= gp[j];
       }
@@ -382,6 +396,7 @@ struct BnBwdParams {
   long M;
   int C, rows_per_sample;
   BnBwdFin fin;          // apply only; fin.partial != null: bcoef is folded from the reduction's partial rows here
+  RowDiv rdiv;           // rows_per_sample as a magic multiplier
 };
 
 // 1024-thread blocks: at most 256 partial rows per launch, which the finalize / bias-sum kernels fold themselves (a
@@ -438,12 +453,12 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
     // tensor read less than re-reading dout and the mask tensor; the values are identical (a masked copy of dout)
     if (p.dz_out) st16((T*)p.dz_out + r * p.C + c0, pack16<T>(d));
     if (p.gate) {
-      const float* gp = p.gate + (r / p.rows_per_sample) * p.C + c0;
+      const float* gp = p.gate + row_div(r, p.rdiv) * p.C + c0;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) d[j] *= gp[j];
     }
     if (p.addc) {
-      const float* ap = p.addc + (r / p.rows_per_sample) * p.C + c0;
+      const float* ap = p.addc + row_div(r, p.rdiv) * p.C + c0;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) d[j] += ap[j];
     }
@@ -1077,12 +1092,12 @@ __global__ void bcast_rows_kernel(const float* __restrict__ v, T* __restrict__ o
 // the same with 16-byte stores: thread = (16-B channel chunk, row slice), one block per CU walking the rows
 template <typename T>
 __global__ __launch_bounds__(1024) void bcast_rows_vec_kernel(const float* __restrict__ v, T* __restrict__ out, long M,
-                                                              int R, int C, float scale) {
+                                                              RowDiv rdiv, int C, float scale) {
   constexpr int VEC = Elem<T>::VEC;
   const int cpr = C / VEC, rpi = 1024 / cpr;
   const int c0 = (threadIdx.x % cpr) * VEC, r0 = threadIdx.x / cpr;
   for (long r = (long)blockIdx.x * rpi + r0; r < M; r += (long)gridDim.x * rpi) {
-    const float* src = v + (r / R) * C + c0;
+    const float* src = v + row_div(r, rdiv) * C + c0;
     float f[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) f[j] = src[j] * scale;
@@ -1306,6 +1321,7 @@ int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, c
   memset(&p, 0, sizeof(p));
   p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
+  p.rdiv = make_row_div(p.rows_per_sample);
   p.fin.partial = f.partial; p.fin.rows = f.rows; p.fin.count = f.count; p.fin.gamma = f.gamma; p.fin.beta = f.beta;
   p.fin.rm = f.rm; p.fin.rv = f.rv; p.fin.nbt = f.nbt; p.fin.momentum = f.momentum; p.fin.eps = f.eps; p.fin.coef_out = coef;
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
@@ -1324,6 +1340,7 @@ int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, con
   memset(&p, 0, sizeof(p));
   p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
+  p.rdiv = make_row_div(p.rows_per_sample);
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
   // (1024-thread blocks, one per CU, each walking rows with a grid stride -- the launch shape of bn_bwd_kernel, which
   // reaches 5.3 TB/s; 256-thread blocks x 4096 reached 4.3: 0.74 ms per step for the 22 launches)
@@ -1369,6 +1386,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   memset(&p, 0, sizeof(p));
   p.dout = dout; p.maskref = maskref; p.gate = gate; p.addc = addc; p.y = y; p.coef = coef; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+  p.rdiv = make_row_div(p.rows_per_sample);
   p.partial = partial;
   const bool dz_early = dy && dz_out && maskref && maskref != y && dz_out != dout;
   if (dz_early) p.dz_out = dz_out;
@@ -1422,6 +1440,7 @@ int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void
   memset(&p, 0, sizeof(p));
   p.dout = dout; p.maskref = maskref; p.y = y; p.coef = coef; p.M = M; p.C = C;
   p.gate = gate; p.addc = addc; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+  p.rdiv = make_row_div(p.rows_per_sample);
   p.bcoef = bcoef; p.dy = dy;
   if (fold) {
     p.fin.partial = partial; p.fin.rows = rows; p.fin.count = (double)M; p.fin.gamma = gamma; p.fin.dgamma = dgamma;
@@ -1579,8 +1598,8 @@ int ecg_bcast_rows(int dtype, const float* v, void* out, int N, int R, int C, fl
     int g = ew_grid(M, (1024 / (C / vecw)) * 4);
     if (g > 256) g = 256;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bcast_rows_vec_kernel<bf16_t>, dim3(g), dim3(1024), 0, stream, v, (bf16_t*)out, M, R, C, scale),
-               hipLaunchKernelGGL(bcast_rows_vec_kernel<float>, dim3(g), dim3(1024), 0, stream, v, (float*)out, M, R, C, scale),
+               hipLaunchKernelGGL(bcast_rows_vec_kernel<bf16_t>, dim3(g), dim3(1024), 0, stream, v, (bf16_t*)out, M, make_row_div(R), C, scale),
+               hipLaunchKernelGGL(bcast_rows_vec_kernel<float>, dim3(g), dim3(1024), 0, stream, v, (float*)out, M, make_row_div(R), C, scale),
                "bcast_rows");
     ECG_CHECK_LAUNCH("bcast_rows_vec");
     return 0;
