@@ -31,6 +31,19 @@ namespace {
 constexpr int HBM_ = 256;        // pixels per workgroup
 constexpr unsigned H_OOB = 0x80000000u;  // stays out of range after a channel-slice offset is added (tensors < 2 GiB)
 
+#ifdef ECG_STAMP
+// Diagnostic build only (make stamp): s_memtime stamps at the phase boundaries of a tile, summed per launch by lane 0 of wave 0
+// of every workgroup: [0] address table, [1] wait for the tile's first fills + barrier, [2] K loop, [3] epilogue, [4] tiles,
+// [5] whole workgroup.  Shares, not lengths (tools/stamp_halo.py).
+__device__ unsigned long long g_hstamp[8];
+#define HSTAMP_AT(t)                                                          \
+  do {                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+  } while (0)
+#endif
+
 struct HaloParams {
   const void* src;
   const void* wpk;
@@ -105,7 +118,10 @@ template <int BN, int NW = 8> struct HaloCfg {
   static constexpr int SBASE = WBASE + NWS * WSTAGE;   // fp32 [4 pixel quarters][2][BN] partial-row accumulators
   static constexpr int CBASE = SBASE + 4 * 2 * BN * 4;   // fp32 [3][BN]: scale, shift, mean of the fused BatchNorm backward
   static constexpr int TRASH = CBASE + 3 * BN * 4;       // 256 B nobody reads: destination of the L2-prefetch DMAs
-  static constexpr int LDS = TRASH + 256;
+  // stream form (64-channel tiles): per-pixel validity masks of the address pairs, [2 tiles][6 pairs (5 used)][256 pixels] dwords
+  static constexpr int MBASE = TRASH + 256;
+  static constexpr int MBUF = 6 * 256 * 4;
+  static constexpr int LDS = MBASE + (BN == 64 && NW == 8 ? 2 * MBUF : 0);
   static constexpr int WPS = BN / (8 * NW);           // weight DMA pieces per wave per step
   static constexpr int NPW_MAX = HCAP / (8 * NW);     // halo DMA pieces per wave per channel slice
   static constexpr int WCN = NW / 4;                   // channel groups of waves
@@ -122,9 +138,19 @@ template <int BN, int NW = 8> struct HaloCfg {
 // s_barrier in front of their K loop, one behind the others'): in every interval one wave of each SIMD issues MFMAs while its
 // partner issues LDS reads / fills, instead of both meeting at the matrix pipe and then both at the LDS.  One fragment
 // register set instead of two.  Same products in the same order: results bit-identical to the lock-step form.
-template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false>
+// ST (round 3): STREAM form of the one-slice (64 -> 64 channel) tiles.  tools/stamp_halo.py (profiles/r03_stamp_halo.txt): of a
+// layer-1 tile's ~11.4 k cycles the K loop is 58 %; the rest is the address table, the wait for the tile's first fills + barrier,
+// and the epilogue -- phases in which the matrix pipe of all four SIMDs idles, 12 times per workgroup.  With one channel slice
+// per tile the weights are the same 9 taps for every tile and the next tile's halo already streams into the other buffer, so the
+// K loop never has to stop: the weight ring runs on across the tile boundary, the step-0 fragments of tile i+1 are read in step 8
+// of tile i, the first MFMA of a tile starts from a zero C operand (no accumulator clearing), the finished accumulators are
+// copied aside and tile i's epilogue (bias / ReLU / statistics / bf16 pack / 16-byte stores) runs in four pieces inside steps
+// 1-4 of tile i+1, and the address table of tile i+1 is rebuilt in place, register pair by register pair, as soon as tile i has
+// used a pair for the last time.  Same products, same order of accumulation, same statistics grouping: bit-identical results.
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(HaloParams p) {
   using C = HaloCfg<BN, NW>;
+  static_assert(!ST || (BN == 64 && RS == 9 && NCS1 && NW == 8 && !PP && MODE != 1), "stream form: 64 -> 64 channel 3x3 tiles, no fused reduction");
   static_assert(!PP || (NW == 8 && !NCS1), "ping-pong: 8-wave workgroups");
   static_assert(!(NCS1 && NW == 4), "one halo buffer: the next tile's halo cannot stream in during the K loop");
   static_assert(NW == 8 || RS % 3 == 0, "3-slot ring: the slot of a step is its tap index mod 3");
@@ -285,6 +311,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     return (u32x4){off, 0x3c003c00u, off, 0x3c003c00u};
 #endif
     return *reinterpret_cast<const u32x4*>(smem + off);
+  };
+  // (fresh: the tile's first MFMA block starts from a zero C operand -- the stream form never clears its accumulators)
+  auto mma_fresh = [&](const u32x4 (&fa)[TC], const u32x4 (&fb)[TP]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                            __builtin_bit_cast(bf16x8_t, fb[b]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
   auto mma = [&](const u32x4 (&fa)[TC], const u32x4 (&fb)[TP]) {
 #if defined(HALO_ABL) && HALO_ABL == 1   // timing-only diagnostic build (make halo_abl): no MFMAs, fragments kept alive
@@ -523,9 +560,248 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     for (int j = 0; j < 8; ++j) rq1[a][j] = rq2[a][j] = 0.f;
   const bool racc = RACC && p.wg_rows != 0;
   bool first_tile = true;
+#ifdef ECG_STAMP
+  unsigned long long hs_a, hs_b, hs_c, hs_d, hs_e, hs_w0, hs_acc[4] = {0, 0, 0, 0}, hs_tiles = 0, hs_bar = 0;
+  HSTAMP_AT(hs_w0);
+#endif
+  if constexpr (ST) {
+    // ---- the stream form (see the kernel's header) ------------------------------------------------------------------
+    // The address table of a tile = the tile-independent valid addresses (avalid) selected against the zero row by per-pixel
+    // validity masks.  Building those masks in every lane for its four pixels (two divisions, six range checks, five mask
+    // pairs each) was ~250 VALU per wave and tile -- and VALU time is exposed here (both waves of a SIMD run the same code at
+    // the same time; tools/conv_bench.py with make halo_abl: 100 VALU per tile cost ~8 % of the kernel).  So the masks of a
+    // tile are built ONCE per pixel by the workgroup's 512 threads (thread -> pixel tid & 255; waves 0-3 pairs 0-2, waves 4-7
+    // pairs 3-4), written to a small LDS table during the previous tile's step 0, and every lane fetches the dword of each of
+    // its (pixel, pair)s -- 4 ds_read_b32 + 4 v_bfi per pair -- when the pair's registers come free.
+    auto produce_masks = [&](int m0_, unsigned buf) {
+      const int pixel = tid & 255;
+      const int q = m0_ + pixel;
+      const int n = (int)(((unsigned long long)(unsigned)q * p.mul_hw) >> p.sh_hw), rem = q - n * HW;
+      const int h = (int)(((unsigned long long)(unsigned)rem * p.mul_w) >> p.sh_w), w = rem - h * p.W;
+      // 3x3, pad 1: tap (r, s) reads row h + r - 1 (forward) or h + 1 - r (input gradient), likewise columns
+      const unsigned first_r = MODE == 0 ? 0x007u : 0x1C0u, last_r = MODE == 0 ? 0x1C0u : 0x007u;
+      const unsigned first_s = MODE == 0 ? 0x049u : 0x124u, last_s = MODE == 0 ? 0x124u : 0x049u;
+      unsigned v = 0x1FFu;
+      v &= h == 0 ? ~first_r : ~0u;
+      v &= h == p.H - 1 ? ~last_r : ~0u;
+      v &= w == 0 ? ~first_s : ~0u;
+      v &= w == p.W - 1 ? ~last_s : ~0u;
+      const int k0 = wc * 3;   // pairs k0 .. k0 + 2 (pair 5 does not exist: its slot is never read)
+      unsigned* tb = reinterpret_cast<unsigned*>(smem + C::MBASE + buf * C::MBUF) + k0 * 256 + pixel;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)v, 2 * (k0 + j), 1) & 0xFFFFu;
+        const unsigned hi = (unsigned)__builtin_amdgcn_sbfe((int)v, 2 * (k0 + j) + 1, 1) & 0xFFFF0000u;   // (tap 9: bit clear)
+        tb[j * 256] = lo | hi;
+      }
+    };
+    unsigned mk[TP];   // masks of the pair being rebuilt: read in front of the step's fragment reads, applied behind its barrier
+    const unsigned mlane = (unsigned)C::MBASE + (unsigned)(wp * 64 + fr) * 4u;
+    auto fetch_masks = [&](int t2, unsigned buf) {
+#pragma unroll
+      for (int b = 0; b < TP; ++b) mk[b] = *reinterpret_cast<const unsigned*>(smem + mlane + buf * C::MBUF + t2 * 1024 + b * 64);
+    };
+    auto rebuild = [&](int t2) {
+      const unsigned zz = zaddr | (zaddr << 16);
+#pragma unroll
+      for (int b = 0; b < TP; ++b) baddr[b][t2] = (avalid[b][t2] & mk[b]) | (zz & ~mk[b]);
+    };
+    // vector-memory operations a wave issues in step t, in this order: the weight piece(s) of step s + 3, the next tile's halo
+    // piece t, one 16-byte store of the previous tile's output (steps 1-4; the first tile issues a 4-byte dummy DMA instead,
+    // so that the counts below are constants).  vmcnt retires in issue order: the wait of step t needs the WEIGHTS issued in
+    // step t - 2 (step t + 1 reads them), so everything younger may stay in flight -- that step's halo piece and store, and
+    // all of steps t - 1 and t.  A store has three and a half steps (~1.2 us) for its write acknowledgement; a halo piece
+    // (HBM) has landed by the wait of step 8 at the latest (pieces are issued in steps 0-5), in front of whose barrier nobody
+    // reads the next tile's halo.
+    constexpr auto st_ = [](int t) { t = (t + RS) % RS; return t >= 1 && t <= 4 ? 1 : 0; };
+    constexpr auto hl_ = [](int t) { t = (t + RS) % RS; return t < C::NPW_MAX ? 1 : 0; };
+    static_assert(C::NPW_MAX <= RS - 1 && HPS == 1, "one halo piece per step, none in the tile's last step");
+    const int cw = n0 + wc * C::CPW;
+    const int cl = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+    f32x4 accp[TC][TP];
+    static_assert(TC == 2, "one channel-tile pair per wave");
+    // one quarter (pixel tile b) of the previous tile's epilogue: the tile-at-once epilogue's arithmetic, value for value
+    auto epi_unit = [&](int b, int m0_) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      f32x4 v0 = accp[0][b], v1 = accp[1][b];
+      if (p.bias) {   // (read when needed: no registers held through the K loop; the convolutions in front of a BatchNorm have none)
+        v0 += *reinterpret_cast<const f32x4*>(p.bias + cw + fq * 4);
+        v1 += *reinterpret_cast<const f32x4*>(p.bias + cw + 16 + fq * 4);
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v0[j] = fmaxf(v0[j], 0.f);
+          v1[j] = fmaxf(v1[j], 0.f);
+        }
+      }
+      if constexpr (MODE == 0) {
+        // statistics: quarter b < 2 sums channel tile b over ALL four pixel tiles (the finished accumulators are all still
+        // there) -- the tile's own sums first, in pixel-tile order, then into the running sums: the tile-at-once epilogue's
+        // grouping, bit for bit, with no partial sums held in registers across steps
+        if (b < TC) {
+          f32x4 t1, t2;
+#pragma unroll
+          for (int bb = 0; bb < TP; ++bb) {
+            f32x4 v = accp[b][bb];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + cw + b * 16 + fq * 4);
+            if (p.act == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              t1[j] = bb == 0 ? v[j] : t1[j] + v[j];
+              t2[j] = __builtin_fmaf(v[j], v[j], bb == 0 ? 0.f : t2[j]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            rs1[b][j] += t1[j];
+            rs2[b][j] += t2[j];
+          }
+        }
+      }
+      const unsigned x0 = pack_bf16x2(v0[0], v0[1]), y0 = pack_bf16x2(v0[2], v0[3]);
+      const unsigned x1 = pack_bf16x2(v1[0], v1[1]), y1 = pack_bf16x2(v1[2], v1[3]);
+      auto lo = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
+#if defined(HALO_ABL) && HALO_ABL == 11   // diagnostic 11 (timing only): epilogue arithmetic kept, its store replaced by a 4-byte DMA
+      asm volatile("" ::"v"(lo[0]), "v"(hi[0]), "v"(lo[1]), "v"(hi[1]));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p.wpk,
+                                       (__attribute__((address_space(3))) void*)(smem + C::TRASH), 4, 0, 0);
+#else
+      *reinterpret_cast<u32x4*>(dst + (size_t)(m0_ + wp * 64 + b * 16 + fr) * p.Cd + cw + cl) = (u32x4){lo[0], hi[0], lo[1], hi[1]};
+#endif
+#endif
+    };
+    auto dummy_vm = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p.wpk,
+                                       (__attribute__((address_space(3))) void*)(smem + C::TRASH), 4, 0, 0);
+#endif
+    };
+    set_baddr(m0);
+    produce_masks(m0, 0u);   // (pair 4 is rebuilt from the table at every tile's step 0, the first tile's too)
+    set_hoff(mt + Gk < p.ntm ? (mt + Gk) * HBM_ : p.M + 4 * HBM_);
+    wait_vmcnt<0>();
+    wait_lds();
+    __builtin_amdgcn_s_barrier();
+    ld_a(fa0, slot_of(g0, 0), 0u);
+#pragma unroll
+    for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, 0) + hbuf_of(qs));
+    bool have_prev = false;
+    int m0_prev = 0;
+    for (;;) {
+      const bool more = mt + Gk < p.ntm;
+      const int m0n = (mt + Gk) * HBM_;   // (past the last tile: what is built from it is never used for a product that is kept)
+      const unsigned hb = hbuf_of(qs), hbn = hbuf_of(qs + 1);
+      const unsigned mcur = (unsigned)(qs & 1);   // this tile's half of the mask table
+#pragma unroll
+      for (int b = 0; b < TP; ++b)
+#pragma unroll
+        for (int t2 = 0; t2 < RSP; ++t2) asm volatile("" : "+v"(baddr[b][t2]));
+#pragma unroll
+      for (int t = 0; t < RS; ++t) {
+        const int s = g0 + t;
+        // (a) k-step 1 of this step; in front of it the masks of the address pair this step rebuilds (the step's LDS wait covers
+        // them): tap 8's pair for THIS tile in step 0 (it was still in use when the others were rebuilt), pairs 0-3 of the next tile
+        if (t == 0) fetch_masks(4, mcur);
+        if (t == 2 || t == 4 || t == 6 || t == 8) fetch_masks(t / 2 - 1, mcur ^ 1u);
+        ld_a(fa1, slot_of(s, t), 64u);
+#pragma unroll
+        for (int b = 0; b < TP; ++b) fb1[b] = ld_b((bad(b, t) ^ 64u) + hb);
+        // (b) this step's vector-memory operations, in the order the wait counts assume
+        dma_w(wrow, slot_of(s + D, (t + D) % RS), 0, (t + D) % RS);
+        if (hl_(t)) dma_halo(hbn, 0, t, t + 1);
+        // Everything else a step does besides feeding the matrix pipe -- a quarter of the previous tile's epilogue (steps 1-4),
+        // the next tile's validity bits (steps 0-1) and address pairs (even steps) -- is VALU work, and the two waves of a SIMD
+        // should not do it at the same time (the matrix pipe would idle for both).  It sits at the END of the step: behind the
+        // barrier waves 0-3 have one MFMA block left and waves 4-7 (one block late, see `late`) two, so waves 0-3 reach it
+        // while their partners issue their second block, and waves 4-7 while waves 0-3 are in the next step's first block.
+        // In vector-memory order the store sits between this step's halo piece and the next step's weights; the step's own
+        // wait comes before it (one operation fewer in flight there).
+        auto extra = [&]() {
+          if (st_(t)) {
+#if defined(HALO_ABL) && HALO_ABL == 10   // diagnostic 10 (timing only): the stream form without its in-loop epilogue pieces (same vm-op counts)
+            dummy_vm();
+#else
+            if (have_prev) epi_unit(t - 1, m0_prev);
+            else dummy_vm();
+#endif
+          }
+          // address table of the next tile, in place: pair t2 is free once step 2 t2 + 1 has read its taps; tap 8 (pair 4) is
+          // first read in step 7, so it is rebuilt at the tile's own start.  Step 0 also builds the NEXT tile's masks (read from
+          // step 2 on: a barrier and every writer's LDS wait lie between; that half of the table was last read a tile ago).
+          if (t == 0) {
+            rebuild(4);
+            produce_masks(m0n, mcur ^ 1u);
+          }
+          if (t == 2) rebuild(0);
+          if (t == 4) rebuild(1);
+          if (t == 6) rebuild(2);
+          if (t == 8) rebuild(3);
+        };
+        // (c) k-step 0
+        if (!late) { if (t == 0) mma_fresh(fa0, fb0); else mma(fa0, fb0); }
+        // (d)
+        // (waves 0-3 have not issued this step's store yet: one operation fewer may be in flight)
+        const int outstanding = hl_(t - 2) + st_(t - 2) + (C::WPS + hl_(t - 1) + st_(t - 1)) + (C::WPS + hl_(t) + st_(t));
+        auto wait_n = [&](int n) {
+          if (n == 1) wait_vmcnt<1>();
+          else if (n == 2) wait_vmcnt<2>();
+          else if (n == 3) wait_vmcnt<3>();
+          else if (n == 4) wait_vmcnt<4>();
+          else if (n == 5) wait_vmcnt<5>();
+          else if (n == 6) wait_vmcnt<6>();
+          else if (n == 7) wait_vmcnt<7>();
+          else if (n == 8) wait_vmcnt<8>();
+          else wait_vmcnt<0>();
+        };
+        wait_n(outstanding - st_(t));
+        wait_lds();
+        __builtin_amdgcn_s_barrier();
+        if (late) { if (t == 0) mma_fresh(fa0, fb0); else mma(fa0, fb0); }
+        // (e) k-step 0 of the next step -- after step 8: of the NEXT TILE's step 0 (its halo buffer, its address table)
+        {
+          const int t1 = (t + 1) % RS;
+          ld_a(fa0, slot_of(s + 1, t1), 0u);
+          const unsigned hb1 = t + 1 < RS ? hb : hbn;
+#pragma unroll
+          for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, t1) + hb1);
+        }
+        // (f) k-step 1
+        mma(fa1, fb1);
+        // (g) the step's VALU work
+        extra();
+      }
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) accp[a][b] = acc[a][b];
+      m0_prev = m0;
+      have_prev = true;
+      g0 += RS;
+      ++qs;
+      if (!more) break;
+      mt += Gk;
+      m0 = mt * HBM_;
+      set_hoff(mt + Gk < p.ntm ? (mt + Gk) * HBM_ : p.M + 4 * HBM_);
+    }
+    // the last tile's epilogue; the ring's fills past the last tile must have landed before the workgroup's LDS is given back
+#pragma unroll
+    for (int b = 0; b < TP; ++b) epi_unit(b, m0_prev);
+    wait_vmcnt<0>();
+  } else
   for (;;) {
+#ifdef ECG_STAMP
+    HSTAMP_AT(hs_a);
+#endif
     set_baddr(m0);
     zero_acc();
+#ifdef ECG_STAMP
+    HSTAMP_AT(hs_b);
+#endif
     if (NCS1) set_hoff(mt + Gk < p.ntm ? (mt + Gk) * HBM_ : p.M + 4 * HBM_);   // next tile's halo offsets (none left: all out of range)
     // This tile's first fills have landed.  They were issued BEFORE the previous tile's output stores, and vmcnt retires
     // in issue order: waiting for "all but the N youngest", N = the store instructions of that epilogue, leaves the
@@ -533,12 +809,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     // really issued -- the statistics rows are a wave-uniform runtime choice; operations hipcc adds on its own (scratch)
     // only make the wait stricter.
     constexpr int N_DATA = TC * TP / 2, N_STAT = 2 * TC;
+#if defined(HALO_ABL) && HALO_ABL == 8     // diagnostic 8 (timing only, wrong results): the tile does not wait for its first weight fills
+    if (first_tile) wait_vmcnt<0>();
+    else wait_vmcnt<N_DATA + D * C::WPS>();
+#elif defined(HALO_ABL) && HALO_ABL == 9   // diagnostic 9 (timing only): no wait at all at the tile's start
+    if (first_tile) wait_vmcnt<0>();
+#else
     if (first_tile) wait_vmcnt<0>();
     else if (MODE == 0 && p.stats && !p.wg_rows) wait_vmcnt<N_DATA + N_STAT>();
     else wait_vmcnt<N_DATA>();
+#endif
     first_tile = false;
+#ifdef ECG_STAMP
+    unsigned long long hs_b2;
+    HSTAMP_AT(hs_b2);
+#endif
     wait_lds();
     __builtin_amdgcn_s_barrier();
+#ifdef ECG_STAMP
+    HSTAMP_AT(hs_c);
+#endif
     using F_ = std::integral_constant<bool, false>;
     using T_ = std::integral_constant<bool, true>;
     if constexpr (PP) {
@@ -566,6 +856,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
       for (int b = 0; b < TP; ++b) asm volatile("" : "+v"(acc[a][b]));
     __builtin_amdgcn_sched_barrier(0);
+#ifdef ECG_STAMP
+    HSTAMP_AT(hs_d);
+#endif
     const bool more = mt + Gk < p.ntm;
     const int mt_cur = mt, m0_cur = m0, n0_cur = n0;
     if (more) {
@@ -668,9 +961,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 s1[a][j] += v0[j];
-                s2[a][j] += v0[j] * v0[j];
+                s2[a][j] = __builtin_fmaf(v0[j], v0[j], s2[a][j]);   // (explicit: the stream form's pieces must round the same way)
                 s1[a + 1][j] += v1[j];
-                s2[a + 1][j] += v1[j] * v1[j];
+                s2[a + 1][j] = __builtin_fmaf(v1[j], v1[j], s2[a + 1][j]);
               }
             }
             const unsigned x0 = pack_bf16x2(v0[0], v0[1]), y0 = pack_bf16x2(v0[2], v0[3]);
@@ -821,8 +1114,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
       for (int b = 0; b < TP; ++b) asm volatile("" ::"v"(acc[a][b]));
 #endif
+#ifdef ECG_STAMP
+    HSTAMP_AT(hs_e);
+    hs_acc[0] += hs_b - hs_a; hs_acc[1] += hs_c - hs_b; hs_bar += hs_c - hs_b2; hs_acc[2] += hs_d - hs_c; hs_acc[3] += hs_e - hs_d; ++hs_tiles;
+#endif
     if (!more) break;
   }
+#ifdef ECG_STAMP
+  if (tid == 0) {
+    unsigned long long hs_w1;
+    HSTAMP_AT(hs_w1);
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_hstamp[i], hs_acc[i]);
+    atomicAdd(&g_hstamp[4], hs_tiles);
+    atomicAdd(&g_hstamp[5], hs_w1 - hs_w0);
+    atomicAdd(&g_hstamp[6], 1ull);
+    atomicAdd(&g_hstamp[7], hs_bar);
+  }
+#endif
   if (RACC && racc && ((MODE == 0 && p.stats) || (MODE == 1 && p.red_y))) {
     // the register sums of all tiles: one 16-lane DPP reduction, into this wave's (zero-filled) LDS slots
     float* lrow = sacc + wp * 2 * BN + wc * C::CPW;
@@ -904,14 +1212,14 @@ int halo_gk(int ntn, int ntm, int wg_per_cu = 1) {
   return Gk < 1 ? 1 : Gk;
 }
 
-template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false>
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false>
 int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   using C = HaloCfg<BN, NW>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS) != hipSuccess)
       ECG_FAIL(ECGMM_ERR_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", C::LDS);
     attr_set[dev] = true;
@@ -923,7 +1231,7 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   // (4-wave workgroups: two per CU)
   const int Gk = halo_gk(q.ntn, q.ntm, NW == 4 ? 2 : 1);
   *rows_out = Gk;
-  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP, ST>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
   return 0;
 }
@@ -935,8 +1243,21 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
 // fused BatchNorm-backward reduction (MODE 1) is never dispatched on 4 waves: it needs 432 B of scratch per lane, and with
 // compiler-inserted scratch traffic inside the counted-vmcnt K loop its partial rows were NOT reproducible run to run once
 // other streams shared the GPU (tools/det_check_mm.py; every scratch-free instantiation is bit-reproducible).
+#ifdef ECG_STAMP
+}  // namespace
+extern "C" int ecgmm_hstamp_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_hstamp), sizeof(g_hstamp)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_hstamp), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace {
+#endif
 int g_halo_w4 = -1;
 int g_halo_pp = -1;       // ping-pong K loop on the 128-channel tiles (-1: read ECGMM_HALO_PP, default on)
+int g_halo_stream = -1;   // stream form of the 64 -> 64 channel 3x3 tiles (-1: read ECGMM_HALO_STREAM, default on)
 int g_halo_stagger = -1;  // waves 4-7 staggered by one MFMA block (-1: read ECGMM_HALO_STAGGER, default on)
 int g_halo_enabled = -1;  // read once from ECGMM_CONV_HALO: 0 = off, 1 = where it is the faster kernel (default), 2 = wherever applicable
 
@@ -950,6 +1271,10 @@ extern "C" int ecgmm_conv_halo_enable(int on) {
 
 extern "C" int ecgmm_conv_halo_pingpong(int on) {
   g_halo_pp = on != 0;
+  return 0;
+}
+extern "C" int ecgmm_conv_halo_stream(int on) {
+  g_halo_stream = on != 0;
   return 0;
 }
 extern "C" int ecgmm_conv_halo_stagger(int on) {
@@ -1038,7 +1363,11 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
     if (mode == 0) rc = launch_halo<64, 9, 0, false, 4>(p, &wg, stream);
     else rc = launch_halo<64, 9, 2, false, 4>(p, &wg, stream);
   } else if (g.R == 3 && !wide && p.ncs == 1 && ncs1_on) {   // the same on one 8-wave workgroup per CU: next tile's halo during the K loop
-    if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
+    // (stream form: forward with per-workgroup statistics rows or none, input gradient without addend / fused reduction)
+    if (g_halo_stream < 0) { const char* e = getenv("ECGMM_HALO_STREAM"); g_halo_stream = !(e && e[0] == '0'); }
+    if (mode == 0 && g_halo_stream && (!p.stats || p.wg_rows) && !p.addend) rc = launch_halo<64, 9, 0, true, 8, false, true>(p, &wg, stream);
+    else if (mode != 0 && g_halo_stream && !p.red_y && !p.addend) rc = launch_halo<64, 9, 2, true, 8, false, true>(p, &wg, stream);
+    else if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
     else if (p.red_y) rc = launch_halo<64, 9, 1, true>(p, &wg, stream);
     else rc = launch_halo<64, 9, 2, true>(p, &wg, stream);
   } else if (wide && g.R == 3 && g_halo_pp) {

@@ -56,6 +56,7 @@ SIGNATURES = {
     "ecgmm_conv_halo_cus": (i32, [i32]),
     "ecgmm_conv_halo_w4": (i32, [i32]),
     "ecgmm_conv_halo_stagger": (i32, [i32]),
+    "ecgmm_conv_halo_stream": (i32, [i32]),
     "ecgmm_conv_halo_pingpong": (i32, [i32]),
     "ecgmm_conv_wgrad_pingpong": (i32, [i32]),
     "ecgmm_conv_wgrad_ring_enable": (i32, [i32]),

@@ -170,6 +170,10 @@ int ecgmm_conv_halo_w4(int on);
  * in front of it, so the two waves of a SIMD alternate between the matrix pipe and the LDS / fill issue instead of meeting
  * there: 1 = on (default), 0 = lock step.  Pure scheduling (bit-identical results).  Start-up value: ECGMM_HALO_STAGGER. */
 int ecgmm_conv_halo_stagger(int on);
+/* Halo conv kernel, 64 -> 64 channel 3x3 tiles (ResNet18 layer 1): STREAM form -- the K loop runs on across tile boundaries
+ * (weight ring, next tile's halo and step-0 fragments already in flight) and a tile's epilogue runs inside the next tile's
+ * first K steps: 1 = on (default), 0 = one tile at a time.  Bit-identical results.  Start-up value: ECGMM_HALO_STREAM. */
+int ecgmm_conv_halo_stream(int on);
 /* Halo conv kernel, 128-channel tiles: ping-pong K loop (each K step as four read | MFMA phases, waves 4-7 one barrier behind
  * waves 0-3, so one wave of every SIMD feeds the matrix pipe while its partner reads LDS / issues fills): 1 = on (default),
  * 0 = the lock-step loop.  Bit-identical results.  Start-up value: ECGMM_HALO_PP. */

@@ -162,3 +162,44 @@ def test_pingpong_conv_loop_is_race_free_under_concurrent_load():
                     assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), (H, Cn, fn.__name__, it)
     finally:
         lib.ecgmm_conv_halo_pingpong(1)
+
+
+def test_stream_form_of_the_layer1_tiles_is_race_free_under_concurrent_load():
+    """The stream form of the 64 -> 64 channel 3x3 tiles (conv_halo_kernel<64, 9, ., NCS1, 8, false, ST>: the K loop runs on across
+    tile boundaries, the previous tile's stores and the next tile's halo / weights all retire through counted vmcnt waits) is a
+    synchronisation structure of its own.  Layer 1 at batch 256 (12.25 tiles per workgroup), forward with per-workgroup statistics
+    rows and input gradient, 12 launches each while another stream streams 1 GB copies through the chip: every launch must
+    reproduce the tile-at-a-time kernel's output AND statistics rows bit for bit."""
+    lib = L.lib()
+    side = torch.cuda.Stream()
+    big_a = torch.empty(256 << 20, device=DEV, dtype=torch.uint8)
+    big_b = torch.empty_like(big_a)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    d = L.ConvDesc(B, 56, 56, 64, 64, 3, 3, 1, 1, 1)
+    n = B * 56 * 56 * 64
+    x = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(64 * 64 * 9, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    try:
+        for kind in ("fwd", "dgrad"):
+            def run(on):
+                lib.ecgmm_conv_halo_stream(on)
+                y = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+                st = torch.zeros(512 * 2 * 64, device=DEV)
+                rows = C.c_int(0)
+                if kind == "fwd":
+                    L.check(lib.ecgmm_conv_fwd_wgrows(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(st), C.byref(rows), 0, stream()))
+                else:
+                    L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y), stream()))
+                return y, st
+            ref, ref_st = run(0)
+            torch.cuda.synchronize()
+            for it in range(12):
+                with torch.cuda.stream(side):
+                    big_b.copy_(big_a, non_blocking=True)
+                    big_a.copy_(big_b, non_blocking=True)
+                y, st = run(1)
+                torch.cuda.synchronize()
+                assert torch.equal(y.view(torch.int16), ref.view(torch.int16)), (kind, it)
+                assert torch.equal(st, ref_st), (kind, it)
+    finally:
+        lib.ecgmm_conv_halo_stream(1)

@@ -775,3 +775,54 @@ def test_adam_matches_torch():
         L.check(lib.ecgmm_adam(ptr(pg), ptr(gg), ptr(m), ptr(v), n, 1e-3, 0.95, 0.999, 1e-8, 0.0, step, 0.5, stream()))
     torch.cuda.synchronize()
     assert torch.allclose(pg.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,H,W,cap,act,use_bias", [(16, 56, 56, 0, 1, 1), (20, 56, 56, 7, 0, 1), (4, 32, 32, 1, 1, 0), (40, 56, 56, 100, 0, 0), (8, 8, 60, 3, 0, 0)])
+def test_stream_form_of_64_channel_halo_tiles_matches_tile_at_a_time(B, H, W, cap, act, use_bias):
+    """conv_halo_kernel's stream form (64 -> 64 channel 3x3 tiles: K loop continuous across tile boundaries, previous tile's
+    epilogue inside the next tile's steps, address table rebuilt in place) against the tile-at-a-time form of the same kernel and
+    against the fp32 reference: one tile per workgroup (no boundary at all), many tiles on few workgroups (CU cap 1 / 3 / 7),
+    tile counts that are not a multiple of the workgroup count, bias + ReLU.  Output, statistics rows and input gradient must be
+    bit-identical between the two forms."""
+    lib = L.lib()
+    lib.ecgmm_conv_halo_enable(2)
+    d = L.ConvDesc(B, H, W, 64, 64, 3, 3, 1, 1, 1)
+    g = torch.Generator(device=DEV).manual_seed(B * 131 + H)
+    n = B * H * W * 64
+    x = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(64 * 64 * 9, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(64, device=DEV, generator=g) if use_bias else None
+    res = {}
+    try:
+        lib.ecgmm_conv_halo_cus(cap)
+        for on in (0, 1):
+            lib.ecgmm_conv_halo_stream(on)
+            y = torch.full((n,), 7.0, device=DEV).to(torch.bfloat16)
+            dx = torch.full((n,), 7.0, device=DEV).to(torch.bfloat16)
+            y2 = torch.full((n,), 7.0, device=DEV).to(torch.bfloat16)
+            st = torch.zeros(600 * 2 * 64, device=DEV)
+            rows = C.c_int(0)
+            L.check(lib.ecgmm_conv_fwd_wgrows(L.BF16, C.byref(d), ptr(x), ptr(w), ptr(bias) if use_bias else None, ptr(y), ptr(st), C.byref(rows), act, stream()))
+            L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(dx), stream()))
+            L.check(lib.ecgmm_conv_fwd(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y2), None, act, stream()))
+            torch.cuda.synchronize()
+            res[on] = (y, st[: rows.value * 2 * 64].clone(), dx, y2, rows.value)
+    finally:
+        lib.ecgmm_conv_halo_cus(0)
+        lib.ecgmm_conv_halo_stream(1)
+        lib.ecgmm_conv_halo_enable(1)
+    assert res[0][4] == res[1][4] and res[1][4] >= 1
+    for i, name in enumerate(["output", "statistics rows", "input gradient", "output without statistics"]):
+        a, b = res[0][i], res[1][i]
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name
+    # ... and both are the convolution: fp32 reference on the same bf16 operands
+    xr = x.float().view(B, H, W, 64).permute(0, 3, 1, 2)
+    wr = w.float().view(64, 3, 3, 64).permute(0, 3, 1, 2)
+    ref = F.conv2d(xr, wr, bias, padding=1)
+    if act:
+        ref = ref.relu()
+    got = res[1][0].float().view(B, H, W, 64).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 6e-3
+    tot = res[1][1].view(-1, 2, 64).sum(0)
+    assert rel_err(tot[0], ref.sum((0, 2, 3))) < 2e-3 or ref.sum((0, 2, 3)).abs().max() < 1.0
+    assert rel_err(tot[1], (ref * ref).sum((0, 2, 3))) < 2e-3

@@ -21,6 +21,7 @@ ap.add_argument("--wgrows", action="store_true", help="forward statistics as one
 ap.add_argument("--pp", type=int, default=-1, help="halo kernel, 128-channel tiles: ping-pong K loop 0 off, 1 on (default)")
 ap.add_argument("--wpp", type=int, default=-1, help="wgrad ring kernel: ping-pong between its two wave groups 0 off, 1 on (default)")
 ap.add_argument("--stagger", type=int, default=-1, help="halo kernel: waves 4-7 one MFMA block late: 0 off, 1 on (default)")
+ap.add_argument("--stream", type=int, default=-1, help="halo kernel, 64 -> 64 channel 3x3 tiles: stream form: 0 off, 1 on (default)")
 a = ap.parse_args()
 if a.lib:
     L.LIB_PATH = a.lib
@@ -41,6 +42,8 @@ if a.pp >= 0:
     lib.ecgmm_conv_halo_pingpong(a.pp)
 if a.wpp >= 0:
     lib.ecgmm_conv_wgrad_pingpong(a.wpp)
+if a.stream >= 0:
+    lib.ecgmm_conv_halo_stream(a.stream)
 if a.stagger >= 0:
     lib.ecgmm_conv_halo_stagger(a.stagger)
 if a.w4 >= 0:
