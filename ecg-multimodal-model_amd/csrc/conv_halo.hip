@@ -146,7 +146,10 @@ template <int BN, int NW = 8> struct HaloCfg {
 // of tile i, the first MFMA of a tile starts from a zero C operand (no accumulator clearing), the finished accumulators are
 // copied aside and tile i's epilogue (bias / ReLU / statistics / bf16 pack / 16-byte stores) runs in four pieces inside steps
 // 1-4 of tile i+1, and the address table of tile i+1 is rebuilt in place, register pair by register pair, as soon as tile i has
-// used a pair for the last time.  Same products, same order of accumulation, same statistics grouping: bit-identical results.
+// used a pair for the last time (validity masks built once per pixel by the whole workgroup, through a small LDS table).  The loop
+// body is branch-free apart from the stagger of waves 4-7.  Same products, same order of accumulation, same statistics grouping:
+// bit-identical results.  Batch 256, layer 1 (tools/conv_bench.py --stream 0|1, profiles/r03_halo_stream.txt): forward with
+// statistics 81 -> 72.5 us, input gradient 91 -> 80 us.
 template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(HaloParams p) {
   using C = HaloCfg<BN, NW>;
@@ -607,8 +610,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
       for (int b = 0; b < TP; ++b) baddr[b][t2] = (avalid[b][t2] & mk[b]) | (zz & ~mk[b]);
     };
     // vector-memory operations a wave issues in step t, in this order: the weight piece(s) of step s + 3, the next tile's halo
-    // piece t, one 16-byte store of the previous tile's output (steps 1-4; the first tile issues a 4-byte dummy DMA instead,
-    // so that the counts below are constants).  vmcnt retires in issue order: the wait of step t needs the WEIGHTS issued in
+    // piece t, one 16-byte store of the previous tile's output (steps 1-4; the first tile stores zeros to its own rows, see
+    // below, so the counts are constants).  vmcnt retires in issue order: the wait of step t needs the WEIGHTS issued in
     // step t - 2 (step t + 1 reads them), so everything younger may stay in flight -- that step's halo piece and store, and
     // all of steps t - 1 and t.  A store has three and a half steps (~1.2 us) for its write acknowledgement; a halo piece
     // (HBM) has landed by the wait of step 8 at the latest (pieces are issued in steps 0-5), in front of whose barrier nobody
@@ -621,20 +624,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     f32x4 accp[TC][TP];
     static_assert(TC == 2, "one channel-tile pair per wave");
     // one quarter (pixel tile b) of the previous tile's epilogue: the tile-at-once epilogue's arithmetic, value for value
+    // (no bias, no activation: the host dispatches the stream form only then -- every convolution in front of a BatchNorm --
+    //  so the pieces are straight-line code the scheduler can place between the MFMAs of the step's last block)
     auto epi_unit = [&](int b, int m0_) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      f32x4 v0 = accp[0][b], v1 = accp[1][b];
-      if (p.bias) {   // (read when needed: no registers held through the K loop; the convolutions in front of a BatchNorm have none)
-        v0 += *reinterpret_cast<const f32x4*>(p.bias + cw + fq * 4);
-        v1 += *reinterpret_cast<const f32x4*>(p.bias + cw + 16 + fq * 4);
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v0[j] = fmaxf(v0[j], 0.f);
-          v1[j] = fmaxf(v1[j], 0.f);
-        }
-      }
+      const f32x4 v0 = accp[0][b], v1 = accp[1][b];
       if constexpr (MODE == 0) {
         // statistics: quarter b < 2 sums channel tile b over ALL four pixel tiles (the finished accumulators are all still
         // there) -- the tile's own sums first, in pixel-tile order, then into the running sums: the tile-at-once epilogue's
@@ -643,12 +637,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
           f32x4 t1, t2;
 #pragma unroll
           for (int bb = 0; bb < TP; ++bb) {
-            f32x4 v = accp[b][bb];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + cw + b * 16 + fq * 4);
-            if (p.act == 1) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
+            const f32x4 v = accp[b][bb];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               t1[j] = bb == 0 ? v[j] : t1[j] + v[j];
@@ -690,8 +679,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     ld_a(fa0, slot_of(g0, 0), 0u);
 #pragma unroll
     for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, 0) + hbuf_of(qs));
-    bool have_prev = false;
-    int m0_prev = 0;
+    // The first tile has no previous tile: its four pieces run on zero accumulators (statistics + 0, exactly) and store zeros to
+    // the first tile's OWN rows, which the same lanes overwrite with the real values a tile later (a thread's stores to one
+    // address stay in order) -- no branch in the loop, constant vector-memory counts.
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+      for (int b = 0; b < TP; ++b) accp[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int m0_prev = m0;
     for (;;) {
       const bool more = mt + Gk < p.ntm;
       const int m0n = (mt + Gk) * HBM_;   // (past the last tile: what is built from it is never used for a product that is kept)
@@ -712,8 +707,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
         for (int b = 0; b < TP; ++b) fb1[b] = ld_b((bad(b, t) ^ 64u) + hb);
         // (b) this step's vector-memory operations, in the order the wait counts assume
+#if !(defined(HALO_ABL) && HALO_ABL == 13)
         dma_w(wrow, slot_of(s + D, (t + D) % RS), 0, (t + D) % RS);
         if (hl_(t)) dma_halo(hbn, 0, t, t + 1);
+#endif
         // Everything else a step does besides feeding the matrix pipe -- a quarter of the previous tile's epilogue (steps 1-4),
         // the next tile's validity bits (steps 0-1) and address pairs (even steps) -- is VALU work, and the two waves of a SIMD
         // should not do it at the same time (the matrix pipe would idle for both).  It sits at the END of the step: behind the
@@ -726,8 +723,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #if defined(HALO_ABL) && HALO_ABL == 10   // diagnostic 10 (timing only): the stream form without its in-loop epilogue pieces (same vm-op counts)
             dummy_vm();
 #else
-            if (have_prev) epi_unit(t - 1, m0_prev);
-            else dummy_vm();
+            epi_unit(t - 1, m0_prev);
 #endif
           }
           // address table of the next tile, in place: pair t2 is free once step 2 t2 + 1 has read its taps; tap 8 (pair 4) is
@@ -758,9 +754,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
           else if (n == 8) wait_vmcnt<8>();
           else wait_vmcnt<0>();
         };
+#if defined(HALO_ABL) && (HALO_ABL == 12 || HALO_ABL == 13)   // diagnostic 12 (timing only, wrong results): no per-step wait / barrier; 13: also no in-loop fills
+        wait_lds();
+#else
         wait_n(outstanding - st_(t));
         wait_lds();
         __builtin_amdgcn_s_barrier();
+#endif
         if (late) { if (t == 0) mma_fresh(fa0, fb0); else mma(fa0, fb0); }
         // (e) k-step 0 of the next step -- after step 8: of the NEXT TILE's step 0 (its halo buffer, its address table)
         {
@@ -770,9 +770,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
           for (int b = 0; b < TP; ++b) fb0[b] = ld_b(bad(b, t1) + hb1);
         }
-        // (f) k-step 1
+        // (f) k-step 1, (g) the step's VALU work.  Both are straight-line code (no branch since the first tile runs its pieces on
+        // zero accumulators), so hipcc schedules the VALU instructions -- and the next step's fragment reads and fills -- between
+        // the MFMAs by itself: layer 1 forward 77.5 -> 72.5 us.  (Explicit sched_group_barrier groups of one MFMA + six VALU on top
+        // of that measured the same forward and 3 % slower input gradient: not kept.)  A reordering of this region's vector-memory
+        // operations cannot break the counted waits: both fills write LDS and stay in source order, the store may move among them.
         mma(fa1, fb1);
-        // (g) the step's VALU work
         extra();
       }
 #pragma unroll
@@ -780,7 +783,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #pragma unroll
         for (int b = 0; b < TP; ++b) accp[a][b] = acc[a][b];
       m0_prev = m0;
-      have_prev = true;
       g0 += RS;
       ++qs;
       if (!more) break;
@@ -1365,8 +1367,8 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
   } else if (g.R == 3 && !wide && p.ncs == 1 && ncs1_on) {   // the same on one 8-wave workgroup per CU: next tile's halo during the K loop
     // (stream form: forward with per-workgroup statistics rows or none, input gradient without addend / fused reduction)
     if (g_halo_stream < 0) { const char* e = getenv("ECGMM_HALO_STREAM"); g_halo_stream = !(e && e[0] == '0'); }
-    if (mode == 0 && g_halo_stream && (!p.stats || p.wg_rows) && !p.addend) rc = launch_halo<64, 9, 0, true, 8, false, true>(p, &wg, stream);
-    else if (mode != 0 && g_halo_stream && !p.red_y && !p.addend) rc = launch_halo<64, 9, 2, true, 8, false, true>(p, &wg, stream);
+    if (mode == 0 && g_halo_stream && (!p.stats || p.wg_rows) && !p.addend && !p.bias && p.act != 1) rc = launch_halo<64, 9, 0, true, 8, false, true>(p, &wg, stream);
+    else if (mode != 0 && g_halo_stream && !p.red_y && !p.addend && !p.bias && p.act != 1) rc = launch_halo<64, 9, 2, true, 8, false, true>(p, &wg, stream);
     else if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
     else if (p.red_y) rc = launch_halo<64, 9, 1, true>(p, &wg, stream);
     else rc = launch_halo<64, 9, 2, true>(p, &wg, stream);

@@ -9,7 +9,7 @@ from ecgmm.hip.functional import ptr, stream
 lib = L.lib()
 lib.ecgmm_conv_halo_enable(2)
 bad = 0
-for (B, H, W, cap, act, use_bias) in [(256, 56, 56, 0, 0, 0), (16, 56, 56, 0, 1, 1), (20, 56, 56, 7, 0, 1), (4, 32, 32, 1, 1, 0), (256, 56, 56, 100, 0, 0), (8, 8, 60, 3, 0, 0)]:
+for (B, H, W, cap, act, use_bias) in [(256, 56, 56, 0, 0, 0), (16, 56, 56, 0, 0, 0), (20, 56, 56, 7, 0, 0), (4, 32, 32, 1, 0, 0), (12, 56, 56, 5, 1, 1), (256, 56, 56, 100, 0, 0), (8, 8, 60, 3, 0, 0)]:
     d = L.ConvDesc(B, H, W, 64, 64, 3, 3, 1, 1, 1)
     g = torch.Generator(device="cuda:0").manual_seed(B * 131 + H)
     x = torch.randn(B * H * W * 64, device="cuda:0", generator=g).to(torch.bfloat16)
