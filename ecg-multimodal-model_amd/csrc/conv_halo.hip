@@ -150,10 +150,11 @@ template <int BN, int NW = 8> struct HaloCfg {
 // body is branch-free apart from the stagger of waves 4-7.  Same products, same order of accumulation, same statistics grouping:
 // bit-identical results.  Batch 256, layer 1 (tools/conv_bench.py --stream 0|1, profiles/r03_halo_stream.txt): forward with
 // statistics 81 -> 72.5 us, input gradient 91 -> 80 us.
-template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false>
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false, bool AD = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(HaloParams p) {
   using C = HaloCfg<BN, NW>;
   static_assert(!ST || (BN == 64 && RS == 9 && NCS1 && NW == 8 && !PP && MODE != 1), "stream form: 64 -> 64 channel 3x3 tiles, no fused reduction");
+  static_assert(!AD || (ST && MODE == 2), "AD = the stream form of the input gradient with a residual addend");
   static_assert(!PP || (NW == 8 && !NCS1), "ping-pong: 8-wave workgroups");
   static_assert(!(NCS1 && NW == 4), "one halo buffer: the next tile's halo cannot stream in during the K loop");
   static_assert(NW == 8 || RS % 3 == 0, "3-slot ring: the slot of a step is its tap index mod 3");
@@ -616,7 +617,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     // all of steps t - 1 and t.  A store has three and a half steps (~1.2 us) for its write acknowledgement; a halo piece
     // (HBM) has landed by the wait of step 8 at the latest (pieces are issued in steps 0-5), in front of whose barrier nobody
     // reads the next tile's halo.
-    constexpr auto st_ = [](int t) { t = (t + RS) % RS; return t >= 1 && t <= 4 ? 1 : 0; };
+    // AD (input gradient + residual addend): a quarter's 16-byte addend load is issued TWO steps ahead of the quarter
+    // (loads in steps 1-4 into two alternating register sets, quarters in steps 3-6: hipcc waits for them itself, with a count
+    // that is exact in this straight-line body), and their lines were pulled into L2 by one 4-byte LDS-DMA per wave in step 5 of
+    // the tile that computed them (a wave's 64 pixels x its 64 bytes: one lane per line) -- a load waited for one step after its
+    // issue, or served from HBM, would stall the whole in-order vmcnt queue.
+    constexpr auto st_ = [](int t) { t = (t + RS) % RS; return AD ? (t >= 3 && t <= 6 ? 1 : 0) : (t >= 1 && t <= 4 ? 1 : 0); };
+    constexpr auto ld_ = [](int t) { t = (t + RS) % RS; return AD && t >= 1 && t <= 4 ? 1 : 0; };
+    constexpr auto pf_ = [](int t) { t = (t + RS) % RS; return AD && t == 5 ? 1 : 0; };
+    constexpr auto ex_ = [=](int t) { return st_(t) + ld_(t) + pf_(t); };   // vector-memory operations of a step's VALU part
     constexpr auto hl_ = [](int t) { t = (t + RS) % RS; return t < C::NPW_MAX ? 1 : 0; };
     static_assert(C::NPW_MAX <= RS - 1 && HPS == 1, "one halo piece per step, none in the tile's last step");
     const int cw = n0 + wc * C::CPW;
@@ -626,9 +635,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     // one quarter (pixel tile b) of the previous tile's epilogue: the tile-at-once epilogue's arithmetic, value for value
     // (no bias, no activation: the host dispatches the stream form only then -- every convolution in front of a BatchNorm --
     //  so the pieces are straight-line code the scheduler can place between the MFMAs of the step's last block)
+    // (ONE 16-byte load per lane in the STORE layout -- the 8 consecutive channels of the pixel this lane stores -- instead of an
+    //  8-byte load per channel tile in the accumulator layout: whole 64-byte runs per pixel; the row swap that builds the store
+    //  layout is its own inverse, so two v_permlane16_swap take the addend back to the accumulators' lanes)
+    u32x4 adv[2];
+    auto load_addend = [&](int b, int m0_) {
+      adv[b & 1] = *reinterpret_cast<const u32x4*>(addend + (size_t)(m0_ + wp * 64 + b * 16 + fr) * p.Cd + cw + cl);
+    };
+    auto prefetch_addend = [&](int m0_) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(addend + (size_t)(m0_ + wp * 64 + lane) * p.Cd + cw),
+                                       (__attribute__((address_space(3))) void*)(smem + C::TRASH), 4, 0, 0);
+#endif
+    };
     auto epi_unit = [&](int b, int m0_) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      const f32x4 v0 = accp[0][b], v1 = accp[1][b];
+      f32x4 v0 = accp[0][b], v1 = accp[1][b];
+      if constexpr (AD) {
+        const u32x4 ao = adv[b & 1];
+        auto ax = __builtin_amdgcn_permlane16_swap(ao[0], ao[2], false, false);   // channels 0-1 of tile 0 | of tile 1
+        auto ay = __builtin_amdgcn_permlane16_swap(ao[1], ao[3], false, false);   // channels 2-3
+        v0 += (f32x4){__uint_as_float(ax[0] << 16), __uint_as_float(ax[0] & 0xFFFF0000u), __uint_as_float(ay[0] << 16), __uint_as_float(ay[0] & 0xFFFF0000u)};
+        v1 += (f32x4){__uint_as_float(ax[1] << 16), __uint_as_float(ax[1] & 0xFFFF0000u), __uint_as_float(ay[1] << 16), __uint_as_float(ay[1] & 0xFFFF0000u)};
+      }
       if constexpr (MODE == 0) {
         // statistics: quarter b < 2 sums channel tile b over ALL four pixel tiles (the finished accumulators are all still
         // there) -- the tile's own sums first, in pixel-tile order, then into the running sums: the tile-at-once epilogue's
@@ -723,9 +752,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #if defined(HALO_ABL) && HALO_ABL == 10   // diagnostic 10 (timing only): the stream form without its in-loop epilogue pieces (same vm-op counts)
             dummy_vm();
 #else
-            epi_unit(t - 1, m0_prev);
+            epi_unit(AD ? t - 3 : t - 1, m0_prev);
 #endif
           }
+          if (ld_(t)) load_addend(t - 1, m0_prev);   // (behind the quarter that used this register set)
+          if (pf_(t)) prefetch_addend(m0);            // this tile's own rows: read from step 1 of the next tile on
           // address table of the next tile, in place: pair t2 is free once step 2 t2 + 1 has read its taps; tap 8 (pair 4) is
           // first read in step 7, so it is rebuilt at the tile's own start.  Step 0 also builds the NEXT tile's masks (read from
           // step 2 on: a barrier and every writer's LDS wait lie between; that half of the table was last read a tile ago).
@@ -741,8 +772,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
         // (c) k-step 0
         if (!late) { if (t == 0) mma_fresh(fa0, fb0); else mma(fa0, fb0); }
         // (d)
-        // (waves 0-3 have not issued this step's store yet: one operation fewer may be in flight)
-        const int outstanding = hl_(t - 2) + st_(t - 2) + (C::WPS + hl_(t - 1) + st_(t - 1)) + (C::WPS + hl_(t) + st_(t));
+        // (this step's own store / loads come behind its wait: they are not in the count)
+        const int outstanding = hl_(t - 2) + ex_(t - 2) + (C::WPS + hl_(t - 1) + ex_(t - 1)) + (C::WPS + hl_(t));
         auto wait_n = [&](int n) {
           if (n == 1) wait_vmcnt<1>();
           else if (n == 2) wait_vmcnt<2>();
@@ -752,12 +783,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
           else if (n == 6) wait_vmcnt<6>();
           else if (n == 7) wait_vmcnt<7>();
           else if (n == 8) wait_vmcnt<8>();
+          else if (n == 9) wait_vmcnt<9>();
+          else if (n == 10) wait_vmcnt<10>();
+          else if (n == 11) wait_vmcnt<11>();
+          else if (n == 12) wait_vmcnt<12>();
           else wait_vmcnt<0>();
         };
 #if defined(HALO_ABL) && (HALO_ABL == 12 || HALO_ABL == 13)   // diagnostic 12 (timing only, wrong results): no per-step wait / barrier; 13: also no in-loop fills
         wait_lds();
 #else
-        wait_n(outstanding - st_(t));
+        wait_n(outstanding);
         wait_lds();
         __builtin_amdgcn_s_barrier();
 #endif
@@ -792,7 +827,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     }
     // the last tile's epilogue; the ring's fills past the last tile must have landed before the workgroup's LDS is given back
 #pragma unroll
-    for (int b = 0; b < TP; ++b) epi_unit(b, m0_prev);
+    for (int b = 0; b < TP; ++b) {
+      if constexpr (AD) load_addend(b, m0_prev);
+      epi_unit(b, m0_prev);
+    }
     wait_vmcnt<0>();
   } else
   for (;;) {
@@ -1214,14 +1252,14 @@ int halo_gk(int ntn, int ntm, int wg_per_cu = 1) {
   return Gk < 1 ? 1 : Gk;
 }
 
-template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false>
+template <int BN, int RS, int MODE, bool NCS1 = false, int NW = 8, bool PP = false, bool ST = false, bool AD = false>
 int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   using C = HaloCfg<BN, NW>;
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP, ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP, ST, AD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS) != hipSuccess)
       ECG_FAIL(ECGMM_ERR_LAUNCH, "conv_halo: cannot reserve %d bytes of LDS", C::LDS);
     attr_set[dev] = true;
@@ -1233,7 +1271,7 @@ int launch_halo(const HaloParams& p, int* rows_out, hipStream_t stream) {
   // (4-wave workgroups: two per CU)
   const int Gk = halo_gk(q.ntn, q.ntm, NW == 4 ? 2 : 1);
   *rows_out = Gk;
-  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP, ST>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, RS, MODE, NCS1, NW, PP, ST, AD>), dim3(Gk * q.ntn), dim3(NW * 64), C::LDS, stream, q);
   ECG_CHECK_LAUNCH("conv_halo_kernel");
   return 0;
 }
@@ -1369,6 +1407,7 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
     if (g_halo_stream < 0) { const char* e = getenv("ECGMM_HALO_STREAM"); g_halo_stream = !(e && e[0] == '0'); }
     if (mode == 0 && g_halo_stream && (!p.stats || p.wg_rows) && !p.addend && !p.bias && p.act != 1) rc = launch_halo<64, 9, 0, true, 8, false, true>(p, &wg, stream);
     else if (mode != 0 && g_halo_stream && !p.red_y && !p.addend && !p.bias && p.act != 1) rc = launch_halo<64, 9, 2, true, 8, false, true>(p, &wg, stream);
+    else if (mode != 0 && g_halo_stream && !p.red_y && p.addend && !p.bias && p.act != 1) rc = launch_halo<64, 9, 2, true, 8, false, true, true>(p, &wg, stream);
     else if (mode == 0) rc = launch_halo<64, 9, 0, true>(p, &wg, stream);
     else if (p.red_y) rc = launch_halo<64, 9, 1, true>(p, &wg, stream);
     else rc = launch_halo<64, 9, 2, true>(p, &wg, stream);

@@ -383,9 +383,11 @@ constexpr int RING_ROWS = 256;
 constexpr int RING_BYTES = RING_ROWS * 128;
 constexpr int RING_D = 3;                      // fills run RING_D steps ahead of the step being computed
 constexpr int RING_NDY = RING_D + 1;           // dy stages (4 KB each)
-constexpr int RING_DY = RING_BYTES;
-constexpr int RING_ZERO = RING_DY + RING_NDY * 4096;  // one all-zero 128-byte row
-constexpr int RING_LDS = RING_ZERO + 128;
+constexpr int RING_DYB = RING_NDY * 4096;
+constexpr int RING_LDS = RING_BYTES + RING_DYB + 128;   // per group: ring, dy stages, one all-zero 128-byte row
+// Workgroup layout (round 3): [ring of group 0 | ring of group 1 | dy stages 0 | dy stages 1 | zero rows] -- every ring starts on a
+// multiple of its own 32 KB, so a fragment address is ((A + rot) & 0x7FFF) | ring base: add + and-or on ABSOLUTE LDS addresses
+// (the reads took `group base + offset` before: one more add per read, 26 reads per step).
 
 // LDS-DMA as inline asm (M0 = LDS byte address of the wave's 1-KiB piece, saved and restored): hipcc does not see these
 // loads, so it neither drains them with an s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 (which it does for
@@ -428,7 +430,14 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
-  unsigned char* const smem = smem_wg + grp * RING_LDS;
+  const unsigned lds_wg = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem_wg;   // LDS address of smem_wg[0]
+  const unsigned ring_at = lds_wg + (unsigned)(grp * RING_BYTES);
+  const unsigned dy_at = lds_wg + (unsigned)(GROUPS * RING_BYTES + grp * RING_DYB);
+  const unsigned zero_at = lds_wg + (unsigned)(GROUPS * (RING_BYTES + RING_DYB) + grp * 128);
+  // (absolute ring addresses are composed with OR: the dynamic LDS segment of this kernel starts at 0 -- it has no static LDS --
+  //  and if a toolchain ever placed it elsewhere the ring would still have to sit on a 32 KB boundary)
+  if ((ring_at & (unsigned)(RING_BYTES - 1)) != 0u) __builtin_trap();
+  auto lds_ptr = [](unsigned a) { return (__attribute__((address_space(3))) unsigned char*)(size_t)a; };
   constexpr int TA = 4;   // wave layout as in wgrad_kernel: all 64 output channels x the wave's own 16 input channels
   // PING-PONG between the two groups (round 3; the two waves of a SIMD are wave w of group 0 and wave w of group 1).  In lock
   // step both groups run a K step's head (fill issue, the dy fragments, 18 tap addresses: no MFMA) together and then
@@ -462,12 +471,11 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int a = 0; a < TA; ++a) acc[t][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if ((tid & 255) < 8) *reinterpret_cast<u32x4*>(smem + RING_ZERO + (tid & 255) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if ((tid & 255) < 8) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(lds_ptr(zero_at + (tid & 255) * 16)) = (u32x4){0u, 0u, 0u, 0u};
 
   // ---- DMA bookkeeping (whole tensors are addressed from their start: the host keeps them under 2 GiB)
   constexpr unsigned OOB = 0xFFFFFFFFu;
   const u32x4 rs_x = ring_rsrc(x, (size_t)p.M * p.Cin * 2), rs_dy = ring_rsrc(dy, (size_t)p.M * p.Cout * 2);
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS address of smem[0]
   const int lrow8 = lane >> 3;
   const unsigned x_pix_bytes = (unsigned)p.Cin * 2u, dy_row_bytes = (unsigned)p.Cout * 2u;
   const int P0 = s_begin * 32;
@@ -479,11 +487,11 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
     const int q = q0 + lrow8;
     const int rrow = q & (RING_ROWS - 1);
     const unsigned src = (unsigned)q * x_pix_bytes + (unsigned)(ci0 + (((lane & 7) ^ C::swz(rrow)) * 8)) * 2u;
-    ring_dma16(rs_x, lds0 + (unsigned)((q0 & (RING_ROWS - 1)) * 128), (q >= 0 && q < p.M) ? src : OOB);
+    ring_dma16(rs_x, ring_at + (unsigned)((q0 & (RING_ROWS - 1)) * 128), (q >= 0 && q < p.M) ? src : OOB);
   };
   auto dy_piece = [&](int stage, int step) {
     const int pix = step * 32 + drow;
-    ring_dma16(rs_dy, lds0 + (unsigned)(RING_DY + stage * 4096 + wv * 1024), pix < p.M ? (unsigned)pix * dy_row_bytes + dy_lane : OOB);
+    ring_dma16(rs_dy, dy_at + (unsigned)(stage * 4096 + wv * 1024), pix < p.M ? (unsigned)pix * dy_row_bytes + dy_lane : OOB);
   };
   // fill group of `step` (2 DMAs per wave): its dy tile, and the 32 ring rows it needs beyond the previous step's window
   auto dma_step = [&](int stage, int step) {
@@ -524,33 +532,87 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
   // under the matrix pipe; in front of the step's first MFMA it was ~100 VALU per wave that both groups executed at the
   // same time with the pipe idle (ablation, layer 2: the kernel without its MFMAs took 57 of 85 us -- the MFMA time sat
   // entirely on top of the rest).
+  // Vector-instruction ISSUE is what bounds this loop (a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles: two
+  // VALU per MFMA are free, every further one costs 4 cycles, for both waves of the SIMD; the loop had 125 VALU per 36 MFMAs and
+  // ran at the 1.8 k cycles per step that predicts).  So the validity of a step's taps is 8 lane masks (row above / below and
+  // column left / right in range, for the lo and the hi pixel) -- 8 compares per step, combined per tap on the SCALAR unit --
+  // instead of four add + compare range checks per tap, and a tap's address is add, and, select.
   unsigned al[NT], ah[NT];
-  auto tap_addr = [&](int t, int oh_l, int ow_l, unsigned rot_, unsigned& a_lo, unsigned& a_hi) {
+  // (the masks are ballots -- 64-bit scalars -- and the select takes its mask from the scalar pair: as `bool`s hipcc turned them
+  //  into 0/1 bytes in vector registers and the loop grew to 139 VALU)
+  typedef unsigned long long lanemask_t;
+  struct TapOk { lanemask_t lo_r[3], lo_c[3], hi_r[3], hi_c[3]; };
+  auto tap_ok = [&](int oh_l, int ow_l) -> TapOk {
     int oh_h = oh_l, ow_h = ow_l + 4;
     if (ow_h >= p.W) { ow_h -= p.W; ++oh_h; }
     if (oh_h >= p.H) oh_h -= p.H;
-    const int r = t / 3, sx = t - r * 3;
-    const bool vl = ((unsigned)(oh_l + r - p.pad_h) < (unsigned)p.H) & ((unsigned)(ow_l + sx - 1) < (unsigned)p.W);
-    const bool vh = ((unsigned)(oh_h + r - p.pad_h) < (unsigned)p.H) & ((unsigned)(ow_h + sx - 1) < (unsigned)p.W);
-    const unsigned zrow = (unsigned)RING_ZERO + (unsigned)(8 * (pq & 1));
-    a_lo = vl ? ((A_lo[t] + rot_) & (RING_BYTES - 1)) : zrow;
-    a_hi = vh ? ((A_hi[t] + rot_) & (RING_BYTES - 1)) : zrow;
+    TapOk k;
+    const lanemask_t all = ~0ull;
+    // filter row r reads image row oh + r - pad_h (pad_h = 1 for three filter rows, 0 for one), column sx reads ow + sx - 1
+    k.lo_r[0] = R == 1 ? all : __builtin_amdgcn_ballot_w64(oh_l >= 1); k.lo_r[1] = all; k.lo_r[2] = __builtin_amdgcn_ballot_w64(oh_l <= p.H - 2);
+    k.hi_r[0] = R == 1 ? all : __builtin_amdgcn_ballot_w64(oh_h >= 1); k.hi_r[1] = all; k.hi_r[2] = __builtin_amdgcn_ballot_w64(oh_h <= p.H - 2);
+    k.lo_c[0] = __builtin_amdgcn_ballot_w64(ow_l >= 1); k.lo_c[1] = all; k.lo_c[2] = __builtin_amdgcn_ballot_w64(ow_l <= p.W - 2);
+    k.hi_c[0] = __builtin_amdgcn_ballot_w64(ow_h >= 1); k.hi_c[1] = all; k.hi_c[2] = __builtin_amdgcn_ballot_w64(ow_h <= p.W - 2);
+    return k;
   };
+  auto sel = [](lanemask_t m, unsigned if_set, unsigned if_clear) -> unsigned {
+    unsigned r_;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r_) : "v"(if_clear), "v"(if_set), "s"(m));
+#else
+    r_ = if_set;
+#endif
+    return r_;
+  };
+  const unsigned zrow = zero_at + (unsigned)(8 * (pq & 1));
+  // (x & 0x7FFF) | ring base as ONE v_and_or_b32: mask from a scalar register, base from a vector register -- with the mask as a
+  // literal (gfx9 VOP3 takes none) hipcc emits v_and + v_or
+  unsigned ring_at_v;
+  const unsigned ring_mask = (unsigned)(RING_BYTES - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mov_b32 %0, %1" : "=v"(ring_at_v) : "s"(ring_at));
+#else
+  ring_at_v = ring_at;
+#endif
+  auto wrap = [&](unsigned x_) -> unsigned {
+    unsigned r_;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r_) : "v"(x_), "s"(ring_mask), "v"(ring_at_v));
+#else
+    r_ = (x_ & ring_mask) | ring_at_v;
+#endif
+    return r_;
+  };
+  auto tap_addr = [&](int t, const TapOk& k, unsigned rot_, unsigned& a_lo, unsigned& a_hi) {
+    const int r = t / 3, sx = t - r * 3;
+    a_lo = sel(k.lo_r[r] & k.lo_c[sx], wrap(A_lo[t] + rot_), zrow);
+    a_hi = sel(k.hi_r[r] & k.hi_c[sx], wrap(A_hi[t] + rot_), zrow);
+  };
+  {
+    const TapOk k0 = tap_ok(st_oh, st_ow);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) tap_addr(t, st_oh, st_ow, 0u, al[t], ah[t]);   // the first step's
+    for (int t = 0; t < NT; ++t) tap_addr(t, k0, 0u, al[t], ah[t]);   // the first step's
+  }
 
-  auto compute = [&](int stage, unsigned rot) {
-    const unsigned char* dyt = smem + RING_DY + stage * 4096;
-    // dy fragments (A operand): the step's own tile, rows 8 fq + q (+ 4), as in wgrad_kernel
+  unsigned dyfrag[TA];
+  {
     const int row = 8 * fq + q4;
     const int sw = C::swz(row);
-    u32x4 fa[TA];
 #pragma unroll
     for (int a = 0; a < TA; ++a) {
       const int byte = (a * 16 + 4 * pq) * 2;
-      const unsigned char* a0 = dyt + row * 128 + ((((byte >> 4) ^ sw)) << 4) + (byte & 15);
-      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0)));
-      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<unsigned char*>(a0 + 512)));
+      dyfrag[a] = (unsigned)(row * 128 + ((((byte >> 4) ^ sw)) << 4) + (byte & 15));
+    }
+  }
+  auto compute = [&](int stage, unsigned rot) {
+    // dy fragments (A operand): the step's own tile, rows 8 fq + q (+ 4), as in wgrad_kernel (per-lane offsets fixed for the kernel)
+    const unsigned dyt = dy_at + (unsigned)(stage * 4096);
+    u32x4 fa[TA];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+      const unsigned a0 = dyt + dyfrag[a];
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_ptr(a0));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_ptr(a0 + 512u));
       uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
       fa[a] = (u32x4){l2.x, l2.y, h2.x, h2.y};
     }
@@ -561,6 +623,7 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
     int n_oh = st_oh + d_oh + (cw ? 1 : 0);
     if (n_oh >= p.H) n_oh -= p.H;
     const unsigned n_rot = (rot + 4096u) & (RING_BYTES - 1);
+    const TapOk nk = tap_ok(n_oh, n_ow);
     (void)rot;
     // the fragment reads run ONE TAP AHEAD of the MFMAs that consume them: with the reads of tap t issued right in front of
     // its MFMAs a wave waited out the LDS latency nine times per step (the kernel ran at ~30 % MFMA-busy whatever its fill scheme)
@@ -569,8 +632,8 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
       fb = (u32x4){al[t], ah[t], 0x3c003c00u, 0x3c003c00u};
       return;
 #endif
-      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + al[t]));
-      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + ah[t]));
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_ptr(al[t]));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_ptr(ah[t]));
       uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
       fb = (u32x4){l2.x, l2.y, h2.x, h2.y};
     };
@@ -590,14 +653,14 @@ __global__ __launch_bounds__(256 * GROUPS) void wgrad_ring_kernel(WgradRingParam
                                                             __builtin_bit_cast(bf16x8_t, cur), acc[t][a], 0, 0, 0);
 #endif
       // (tap t's addresses were consumed by rd_tap(t) one iteration ago: replace them by the next step's, under these MFMAs)
-      if (t >= 1) tap_addr(t - 1, n_oh, n_ow, n_rot, al[t - 1], ah[t - 1]);
+      if (t >= 1) tap_addr(t - 1, nk, n_rot, al[t - 1], ah[t - 1]);
       if (PP_OK && t == PP_SPLIT - 1 && pp) {   // the ping-pong's mid-step barrier (the K loop below)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    tap_addr(NT - 1, n_oh, n_ow, n_rot, al[NT - 1], ah[NT - 1]);
+    tap_addr(NT - 1, nk, n_rot, al[NT - 1], ah[NT - 1]);
     st_oh = n_oh;
     st_ow = n_ow;
   };
@@ -799,10 +862,13 @@ int pick_nsplit(const ConvGeom& g, int kp, int groups) {
   // One resident round.  Alone on the GPU a launch wants every CU (512 four-wave slots); on the weight-gradient SIDE
   // stream it runs beside the critical path's dgrad -> BatchNorm chain, and -- an 8-wave, 144 KB-LDS workgroup shares
   // its CU with nothing -- every CU it holds is one the chain waits for.  Narrow (half the CUs, twice as long) the step is
-  // 0.2 ms faster: sweep 512 / 384 / 256 / 192 / 128 slots = 7.39 / 7.24 / 7.18 / 7.21 / 7.82 ms per step, and the slabs
-  // shrink with the split count.  ECGMM_WGRAD_WGS overrides.
+  // 0.2 ms faster: sweep 512 / 384 / 256 / 192 / 128 slots = 7.39 / 7.24 / 7.18 / 7.21 / 7.82 ms per step (round 2), and the
+  // slabs shrink with the split count.  Round 3, after the conv and weight-gradient kernels got faster (same-call sweep,
+  // tools/ab_env.sh): 384 / 320 / 256 / 224 / 192 / 160 slots = 6.95 / 6.93 / 6.88 / 6.84 / 6.81 / 6.85 ms -- the dgrad ->
+  // BatchNorm chain is the critical path of the backward and the side stream has slack, so it gets 96 of the 256 CUs.
+  // ECGMM_WGRAD_WGS overrides.
   static const int slots_env = [] { const char* e = getenv("ECGMM_WGRAD_WGS"); return e ? atoi(e) : 0; }();
-  const int slots = slots_env > 0 ? slots_env : (g_wgrad_narrow ? 256 : 512);
+  const int slots = slots_env > 0 ? slots_env : (g_wgrad_narrow ? 192 : 512);
   int want = ceil_div(slots / groups, tiles);
   int ns = want < 1 ? 1 : want;
   if (ns > steps) ns = steps;

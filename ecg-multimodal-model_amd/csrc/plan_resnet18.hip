@@ -27,6 +27,7 @@ bool stem_recompute(int dtype) {
   if (g_stem_recompute < 0) { const char* e = getenv("ECGMM_STEM_RECOMPUTE"); g_stem_recompute = (e && e[0] == '1'); }
   return g_stem_recompute != 0 && ecg_stem_fused_ok(dtype, 3, 7);
 }
+constexpr long FUSE_NEVER = 1L << 40;
 long g_fuse_min_m = -1;  // pixel-count threshold of the fused BatchNorm-backward reductions (-1: read ECGMM_BN_FUSE_MIN_M)
 
 struct BlockCfg {
@@ -467,13 +468,17 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
       bool fused2 = false;
       int fused2_rows = 0;
       // (ECGMM_BN_FUSE=0: always the separate reduction pass -- A/B switch; same results up to fp32 summation order)
-      // Fused only where it pays (serialized trace, profiles/r02_*_v1): on the 56x56 tensors the reduction pass it
-      // replaces costs more HBM time (52 us) than the epilogue adds (20-30 us); from 28x28 down the epilogue's exposed
+      // Round 2 fused it where it paid then (serialized trace, profiles/r02_*_v1): on the 56x56 tensors the reduction pass
+      // it replaces cost more HBM time (52 us) than the epilogue added (20-30 us); from 28x28 down the epilogue's exposed
       // load latency (one persistent workgroup per CU, 3-4 tiles each) costs MORE than the 10-30 us pass.
-      // ECGMM_BN_FUSE_MIN_M overrides the pixel-count threshold (0 = fuse wherever possible).
+      // Round 3: DEFAULT OFF everywhere.  The fused epilogue is ~500 VALU per wave and tile (137 us per layer-1 launch), the
+      // stream form of the same input gradient without it takes 82 us (101 with the residual addend) + the 50 us pass:
+      // same-call A/B of the whole step, fused on layer 1 / never fused = 6.84, 6.88 / 6.75, 6.75 ms.
+      // ECGMM_BN_FUSE_MIN_M (ecgmm_bn_fuse_min_pixels) sets the pixel-count threshold: 400000 = round 2's choice (layer 1 at
+      // batch 256), 0 = fuse wherever possible.
       static const bool fuse_on = [] { const char* e = getenv("ECGMM_BN_FUSE"); return !(e && e[0] == '0'); }();
       static const bool fold_on = [] { const char* e = getenv("ECGMM_DOWN_FOLD"); return !(e && e[0] == '0'); }();
-      if (g_fuse_min_m < 0) { const char* e = getenv("ECGMM_BN_FUSE_MIN_M"); g_fuse_min_m = e ? atol(e) : 400000L; }
+      if (g_fuse_min_m < 0) { const char* e = getenv("ECGMM_BN_FUSE_MIN_M"); g_fuse_min_m = e ? atol(e) : FUSE_NEVER; }
       const long fuse_min_m = g_fuse_min_m;
       const bool fuse_here = fuse_on && M >= fuse_min_m;
       if (fuse_here && i + 1 < 8 && !r.blk[i + 1].down) {
@@ -594,6 +599,6 @@ extern "C" int ecgmm_stem_recompute(int on) {
 }
 
 extern "C" int ecgmm_bn_fuse_min_pixels(int64_t m) {
-  g_fuse_min_m = m < 0 ? 400000L : (long)m;
+  g_fuse_min_m = m < 0 ? FUSE_NEVER : (long)m;
   return 0;
 }

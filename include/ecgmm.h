@@ -299,8 +299,10 @@ int ecgmm_bn_bwd_from_rows(int dtype, const void* dout, const void* maskref, con
                            int64_t M, int C, void* scratch, void* stream);
 
 /* ResNet18 plan: a BatchNorm-backward reduction is fused into the producing dgrad's epilogue only for layers with at
- * least this many output pixels (default 400000 = the 56x56 stage at batch >= 128; 0 = wherever the halo kernel runs;
- * negative restores the default).  Start-up value: ECGMM_BN_FUSE_MIN_M.  Results differ by fp32 summation order only. */
+ * least this many output pixels.  Default (and any negative m): never -- since round 3 the stream form of the layer-1 input
+ * gradient plus the separate reduction pass is faster than the fused epilogue; 400000 = the 56x56 stage at batch >= 128
+ * (round 2's default), 0 = wherever the halo kernel runs.  Start-up value: ECGMM_BN_FUSE_MIN_M.  Results differ by fp32
+ * summation order only. */
 int ecgmm_bn_fuse_min_pixels(int64_t m);
 /* BatchNorm finalize folded into its consumer pass (every workgroup of bn_act / the backward's apply pass folds the <= 512
  * partial rows itself instead of a separate ~5 us launch in between; csrc/elementwise.hip): 1 = on (default), 0 = separate

@@ -792,6 +792,7 @@ def test_stream_form_of_64_channel_halo_tiles_matches_tile_at_a_time(B, H, W, ca
     x = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16)
     w = (torch.randn(64 * 64 * 9, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(64, device=DEV, generator=g) if use_bias else None
+    add = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16)
     res = {}
     try:
         lib.ecgmm_conv_halo_cus(cap)
@@ -805,14 +806,16 @@ def test_stream_form_of_64_channel_halo_tiles_matches_tile_at_a_time(B, H, W, ca
             L.check(lib.ecgmm_conv_fwd_wgrows(L.BF16, C.byref(d), ptr(x), ptr(w), ptr(bias) if use_bias else None, ptr(y), ptr(st), C.byref(rows), act, stream()))
             L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(dx), stream()))
             L.check(lib.ecgmm_conv_fwd(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y2), None, act, stream()))
+            dxa = torch.full((n,), 7.0, device=DEV).to(torch.bfloat16)
+            L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(x), ptr(w), ptr(add), ptr(dxa), stream()))
             torch.cuda.synchronize()
-            res[on] = (y, st[: rows.value * 2 * 64].clone(), dx, y2, rows.value)
+            res[on] = (y, st[: rows.value * 2 * 64].clone(), dx, y2, rows.value, dxa)
     finally:
         lib.ecgmm_conv_halo_cus(0)
         lib.ecgmm_conv_halo_stream(1)
         lib.ecgmm_conv_halo_enable(1)
     assert res[0][4] == res[1][4] and res[1][4] >= 1
-    for i, name in enumerate(["output", "statistics rows", "input gradient", "output without statistics"]):
+    for i, name in ((0, "output"), (1, "statistics rows"), (2, "input gradient"), (3, "output without statistics"), (5, "input gradient + residual addend")):
         a, b = res[0][i], res[1][i]
         assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name
     # ... and both are the convolution: fp32 reference on the same bf16 operands
@@ -823,6 +826,9 @@ def test_stream_form_of_64_channel_halo_tiles_matches_tile_at_a_time(B, H, W, ca
         ref = ref.relu()
     got = res[1][0].float().view(B, H, W, 64).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 6e-3
+    # the addend form = the plain input gradient + the addend, rounded once
+    want = (res[1][2].float() * 0 + (res[1][5].float() - add.float()))
+    assert rel_err(want, res[1][2].float()) < 1.5e-2
     tot = res[1][1].view(-1, 2, 64).sum(0)
     assert rel_err(tot[0], ref.sum((0, 2, 3))) < 2e-3 or ref.sum((0, 2, 3)).abs().max() < 1.0
     assert rel_err(tot[1], (ref * ref).sum((0, 2, 3))) < 2e-3

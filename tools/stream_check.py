@@ -15,6 +15,7 @@ for (B, H, W, cap, act, use_bias) in [(256, 56, 56, 0, 0, 0), (16, 56, 56, 0, 0,
     x = torch.randn(B * H * W * 64, device="cuda:0", generator=g).to(torch.bfloat16)
     w = (torch.randn(64 * 64 * 9, device="cuda:0", generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(64, device="cuda:0", generator=g) if use_bias else None
+    add = torch.randn(B * H * W * 64, device="cuda:0", generator=g).to(torch.bfloat16)
     lib.ecgmm_conv_halo_cus(cap)
     res = {}
     for on in (0, 1):
@@ -25,18 +26,20 @@ for (B, H, W, cap, act, use_bias) in [(256, 56, 56, 0, 0, 0), (16, 56, 56, 0, 0,
         n = C.c_int(0)
         L.check(lib.ecgmm_conv_fwd_wgrows(L.BF16, C.byref(d), ptr(x), ptr(w), ptr(bias) if use_bias else None, ptr(y), ptr(st), C.byref(n), act, stream()))
         L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(dx), stream()))
+        dxa = torch.full((B * H * W * 64,), 7.0, device="cuda:0").to(torch.bfloat16)
+        L.check(lib.ecgmm_conv_bwd_data(L.BF16, C.byref(d), ptr(x), ptr(w), ptr(add), ptr(dxa), stream()))
         y2 = torch.full((B * H * W * 64,), 7.0, device="cuda:0").to(torch.bfloat16)
         L.check(lib.ecgmm_conv_fwd(L.BF16, C.byref(d), ptr(x), ptr(w), None, ptr(y2), None, act, stream()))
         torch.cuda.synchronize()
-        res[on] = (y.clone(), st[: n.value * 2 * 64].clone(), dx.clone(), y2.clone(), n.value)
-    ok = all(torch.equal(res[0][i].view(torch.int16) if res[0][i].dtype == torch.bfloat16 else res[0][i], res[1][i].view(torch.int16) if res[1][i].dtype == torch.bfloat16 else res[1][i]) for i in range(4)) and res[0][4] == res[1][4]
-    for i, nm in enumerate(["y+rows", "rows", "dx", "y(no stats)"]):
+        res[on] = (y.clone(), st[: n.value * 2 * 64].clone(), dx.clone(), y2.clone(), n.value, dxa.clone())
+    ok = all(torch.equal(res[0][i].view(torch.int16) if res[0][i].dtype == torch.bfloat16 else res[0][i], res[1][i].view(torch.int16) if res[1][i].dtype == torch.bfloat16 else res[1][i]) for i in (0, 1, 2, 3, 5)) and res[0][4] == res[1][4]
+    for i, nm in ((0, "y+rows"), (1, "rows"), (2, "dx"), (3, "y(no stats)"), (5, "dx+addend")):
         a_, b_ = res[0][i].float(), res[1][i].float()
         if a_.shape == b_.shape and not torch.equal(a_, b_):
             df = (a_ != b_).nonzero().flatten()
             per = 256 * 64 if nm != "rows" else 128
             print(f"   {nm}: {df.numel()} of {a_.numel()} differ, first at {df[0].item()} (tile/row {df[0].item() // per}, offset {df[0].item() % per}), last tile {df[-1].item() // per}, max |d| {(a_ - b_).abs().max().item():.3e}, tiles hit {torch.unique(df // per).numel()}")
-    fin = all(torch.isfinite(res[1][i].float()).all().item() for i in range(4))
+    fin = all(torch.isfinite(res[1][i].float()).all().item() for i in (0, 1, 2, 3, 5))
     print(f"B={B} {H}x{W} cap={cap} act={act} bias={use_bias}: rows {res[1][4]}  identical={ok} finite={fin}  |y|={res[1][0].float().abs().mean().item():.4f}")
     bad += (not ok) or (not fin)
 lib.ecgmm_conv_halo_cus(0)
