@@ -855,6 +855,7 @@ int launch_wgrad_ring(const WgradRingParams& p, dim3 grid, hipStream_t stream) {
 }
 
 bool g_wgrad_narrow = false;
+int g_wgrad_narrow_slots = 256;
 int pick_nsplit(const ConvGeom& g, int kp, int groups) {
   long M = (long)g.N * g.OH * g.OW;
   int tiles = ceil_div(g.Cout, 64) * ceil_div(g.Cin, 64);
@@ -863,12 +864,14 @@ int pick_nsplit(const ConvGeom& g, int kp, int groups) {
   // stream it runs beside the critical path's dgrad -> BatchNorm chain, and -- an 8-wave, 144 KB-LDS workgroup shares
   // its CU with nothing -- every CU it holds is one the chain waits for.  Narrow (half the CUs, twice as long) the step is
   // 0.2 ms faster: sweep 512 / 384 / 256 / 192 / 128 slots = 7.39 / 7.24 / 7.18 / 7.21 / 7.82 ms per step (round 2), and the
-  // slabs shrink with the split count.  Round 3, after the conv and weight-gradient kernels got faster (same-call sweep,
-  // tools/ab_env.sh): 384 / 320 / 256 / 224 / 192 / 160 slots = 6.95 / 6.93 / 6.88 / 6.84 / 6.81 / 6.85 ms -- the dgrad ->
-  // BatchNorm chain is the critical path of the backward and the side stream has slack, so it gets 96 of the 256 CUs.
-  // ECGMM_WGRAD_WGS overrides.
+  // slabs shrink with the split count.  Round 3, after the conv and weight-gradient kernels got faster (same-call sweep of the
+  // multimodal step at batch 256, tools/ab_env.sh): 384 / 320 / 256 / 224 / 192 / 160 slots = 6.95 / 6.93 / 6.88 / 6.84 / 6.81 /
+  // 6.85 ms -- there the dgrad -> BatchNorm chain is the critical path of the backward and the side stream has slack, so the
+  // ResNet18 plan asks for 192 (96 of the 256 CUs) from batch 192 up; the image-only step at batch 128 (3.445 / 3.48 ms) and
+  // the 12-lead signal encoder at batch 512 (2.95 / 3.13 ms) are faster at 256 and keep it (the caller's choice:
+  // ecg_conv_wgrad_narrow's second argument).  ECGMM_WGRAD_WGS overrides.
   static const int slots_env = [] { const char* e = getenv("ECGMM_WGRAD_WGS"); return e ? atoi(e) : 0; }();
-  const int slots = slots_env > 0 ? slots_env : (g_wgrad_narrow ? 192 : 512);
+  const int slots = slots_env > 0 ? slots_env : (g_wgrad_narrow ? g_wgrad_narrow_slots : 512);
   int want = ceil_div(slots / groups, tiles);
   int ns = want < 1 ? 1 : want;
   if (ns > steps) ns = steps;
@@ -893,7 +896,7 @@ extern "C" int ecgmm_conv_wgrad_ring_enable(int on) {
 }
 
 // narrow = the caller runs its weight gradients on a side stream beside other work (see pick_nsplit)
-void ecg_conv_wgrad_narrow(bool narrow) { g_wgrad_narrow = narrow; }
+void ecg_conv_wgrad_narrow(bool narrow, int slots) { g_wgrad_narrow = narrow; g_wgrad_narrow_slots = slots > 0 ? slots : 256; }
 
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g) {
   const bool keep = g_wgrad_narrow;

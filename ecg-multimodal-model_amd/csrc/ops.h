@@ -34,7 +34,7 @@ int ecg_conv_halo(int mode, const ConvGeom& g, const void* src, const void* wpk,
                   const void* addend, float* stats, int act, ConvEpi* epi, hipStream_t stream);
 // conv_wgrad.hip
 size_t ecg_conv_wgrad_workspace(int dtype, const ConvGeom& g);
-void ecg_conv_wgrad_narrow(bool narrow);
+void ecg_conv_wgrad_narrow(bool narrow, int slots = 256);   // slots: four-wave slots of a narrow launch (conv_wgrad.hip, pick_nsplit)
 int ecg_conv_wgrad(int dtype, const ConvGeom& g, const void* x, const void* dy, float* grad_oihw, int accumulate,
                    void* workspace, size_t workspace_bytes, hipStream_t stream);
 // conv_stem.hip

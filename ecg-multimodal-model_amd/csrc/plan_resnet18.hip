@@ -434,7 +434,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   ECG_TRY(side_init());
   const bool side = g_side.enabled;
   // weight gradients of this call run beside the dgrad chain: narrow launches (conv_wgrad.hip, pick_nsplit)
-  ecg_conv_wgrad_narrow(side);
+  ecg_conv_wgrad_narrow(side, N >= 192 ? 192 : 256);
   struct NarrowOff { ~NarrowOff() { ecg_conv_wgrad_narrow(false); } } narrow_off;
   hipStream_t ws = side ? g_side.s : s;  // stream of the weight-gradient kernels
 
