@@ -121,9 +121,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   constexpr bool PAR = (MODE == 1 && ST == 2);
   constexpr int TSTEP = PAR ? 2 : 1;
   int ph = 0, pw = 0, Hc = p.Hd, Wc = p.Wd, r0 = 0, s0 = 0, Rc = p.R, Sc = p.S, Mc = p.M;
+  // (grid slices are dispatched in blockIdx.z order: the class with the MOST taps -- (1,1): four of a 3x3 filter -- goes first and
+  //  the one-tap class last, so the launch's tail is made of its shortest workgroups: batch 256, layers 2 / 3 / 4 input gradient
+  //  87 / 63 / 66 -> 83 / 59 / 54 us.  One-row tensors (the 1-D encoder: classes 2 and 3 are empty) keep the plain order, which
+  //  measured 10 % faster there.)
+  const int cz = PAR ? (p.Hd > 1 ? 3 - (int)blockIdx.z : (int)blockIdx.z) : 0;
   if (PAR) {
-    ph = blockIdx.z >> 1;
-    pw = blockIdx.z & 1;
+    ph = cz >> 1;
+    pw = cz & 1;
     Hc = (p.Hd - ph + 1) >> 1;
     Wc = (p.Wd - pw + 1) >> 1;
     r0 = (ph + p.pad_h) & 1;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
     if (m0 >= Mc) return;  // block-uniform
   }
   const int HWd = Hc * Wc;
-  const int cls = PAR ? (int)blockIdx.z : 0;
+  const int cls = PAR ? cz : 0;
   const unsigned mhw = p.mul_hw[cls], shw = p.sh_hw[cls], mw = p.mul_w[cls], sw_ = p.sh_w[cls];
   auto div_hw = [&](int x) -> int { return (int)(((unsigned long long)(unsigned)x * mhw) >> shw); };
   auto div_w = [&](int x) -> int { return (int)(((unsigned long long)(unsigned)x * mw) >> sw_); };
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(IgemmParams p) {
   const int RS = p.R * p.S;
   const int cpt = (p.Cs + KBE - 1) / KBE;  // stages per tap
   const int nk_main = Rc * Sc * cpt;
-  const bool has2 = PAR && p.src2 != nullptr && blockIdx.z == 0;   // block-uniform
+  const bool has2 = PAR && p.src2 != nullptr && cz == 0;   // block-uniform
   const int nk = nk_main + (has2 ? cpt : 0);
   unsigned wrow[NWV];
 #pragma unroll
