@@ -320,6 +320,8 @@ struct BnActParams {
   int C, rows_per_sample, relu;
   BnFin fin;               // fin.partial != null: the coefficients are folded from the producer's partial rows here
   RowDiv rdiv;             // rows_per_sample as a magic multiplier
+  unsigned char* relu_bits;  // nullable (bf16, relu): bit j of byte [row][chunk] = (out[row][8 chunk + j] > 0) -- the ReLU mask the
+                             // BatchNorm backward of a residual block needs, at 1/16 of the activated tensor's bytes
 };
 
 #ifndef BN_ACT_THREADS
@@ -384,6 +386,16 @@ __global__ __launch_bounds__(BN_ACT_THREADS) void bn_act_kernel(BnActParams p) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) f[j] = fmaxf(f[j], 0.f);
       }
+      if (VEC == 8 && p.relu_bits && (u == 0 || two)) {
+        // (> 0 of the value as STORED: a positive fp32 value below the smallest bf16 rounds to 0 and is masked out by the
+        //  backward that compares the stored tensor, too)
+        float g[VEC];
+        unpack16<T>(pack16<T>(f), g);
+        unsigned bits = 0u;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bits |= (g[j] > 0.f ? 1u : 0u) << j;
+        p.relu_bits[rr * cpr + chunk] = (unsigned char)bits;
+      }
       if (u == 0 || two) st16(out + rr * p.C + c0, pack16<T>(f));
     }
   }
@@ -410,6 +422,7 @@ struct BnBwdParams {
   int C, rows_per_sample;
   BnBwdFin fin;          // apply only; fin.partial != null: bcoef is folded from the reduction's partial rows here
   RowDiv rdiv;           // rows_per_sample as a magic multiplier
+  const unsigned char* mask_bits;   // nullable (bf16): the ReLU mask as bits (BnActParams::relu_bits) instead of maskref
 };
 
 // 1024-thread blocks: at most 256 partial rows per launch, which the finalize / bias-sum kernels fold themselves (a
@@ -456,6 +469,10 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
       // BatchNorm affine instead of reading the activated tensor (one tensor read less)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) d[j] = (v[j] * msc[j] + msh[j]) > 0.f ? d[j] : 0.f;
+    } else if (VEC == 8 && p.mask_bits) {
+      const unsigned bits = p.mask_bits[r * (p.C / VEC) + c0 / VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[j] = (bits >> j) & 1u ? d[j] : 0.f;
     } else if (mref) {
       unpack16<T>(ld16s(mref + r * p.C + c0), m);
 #pragma unroll
@@ -1327,7 +1344,8 @@ bool ecg_bn_fold_ok(int C, int rows) {
 // bn_act whose coefficients are folded from the producer's partial rows inside the launch (no bn_finalize launch);
 // `coef` is an OUTPUT here (workgroup 0 writes it for the backward), as are the running statistics.
 int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, const void* res, const float* rcoef,
-                    const float* gate, int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream) {
+                    const float* gate, int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream,
+                    unsigned char* relu_bits) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act: C=%d unsupported", C);
   if (!ecg_bn_fold_ok(C, f.rows)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act_fold: C=%d rows=%d not foldable", C, f.rows);
   BnActParams p;
@@ -1337,6 +1355,7 @@ int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, c
   p.rdiv = make_row_div(p.rows_per_sample);
   p.fin.partial = f.partial; p.fin.rows = f.rows; p.fin.count = f.count; p.fin.gamma = f.gamma; p.fin.beta = f.beta;
   p.fin.rm = f.rm; p.fin.rv = f.rv; p.fin.nbt = f.nbt; p.fin.momentum = f.momentum; p.fin.eps = f.eps; p.fin.coef_out = coef;
+  p.relu_bits = dtype == ECGMM_BF16 && relu ? relu_bits : nullptr;
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
   int grid = ew_grid(M, (BN_ACT_THREADS / (C / vec)) * 4);
   if (grid > 256) grid = 256;
@@ -1347,13 +1366,14 @@ int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, c
 }
 
 int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
-               int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream) {
+               int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream, unsigned char* relu_bits) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_act: C=%d unsupported", C);
   BnActParams p;
   memset(&p, 0, sizeof(p));
   p.y = y; p.coef = coef; p.res = res; p.rcoef = rcoef; p.gate = gate; p.out = out; p.M = M; p.C = C;
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; p.relu = relu;
   p.rdiv = make_row_div(p.rows_per_sample);
+  p.relu_bits = dtype == ECGMM_BF16 && relu ? relu_bits : nullptr;
   int vec = dtype == ECGMM_BF16 ? 8 : 4;
   // (1024-thread blocks, one per CU, each walking rows with a grid stride -- the launch shape of bn_bwd_kernel, which
   // reaches 5.3 TB/s; 256-thread blocks x 4096 reached 4.3: 0.74 ms per step for the 22 launches)
@@ -1390,8 +1410,10 @@ size_t ecg_bn_bwd_scratch(int dtype, long M, int C) {
 
 int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
                int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma, float* dbeta,
-               void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream) {
+               void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream,
+               const unsigned char* mask_bits) {
   if (!chunk_ok(C, dtype)) ECG_FAIL(ECGMM_ERR_SHAPE, "bn_bwd: C=%d unsupported", C);
+  if (dtype != ECGMM_BF16 || maskref == y) mask_bits = nullptr;
   int grid = bn_bwd_rows(dtype, M, C);
   float* partial = scratch;
   float* bcoef = scratch + (size_t)(grid + ECG_TAIL_ROWS) * 2 * C;
@@ -1401,7 +1423,8 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
   p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
   p.rdiv = make_row_div(p.rows_per_sample);
   p.partial = partial;
-  const bool dz_early = dy && dz_out && maskref && maskref != y && dz_out != dout;
+  p.mask_bits = mask_bits;
+  const bool dz_early = dy && dz_out && (mask_bits || (maskref && maskref != y)) && dz_out != dout;
   if (dz_early) p.dz_out = dz_out;
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, false>(p, grid, stream)), (bn_bwd_launch<float, false>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_reduce");
@@ -1421,7 +1444,7 @@ int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* ga
     p.fin.partial = partial; p.fin.rows = grid; p.fin.count = (double)M; p.fin.gamma = gamma; p.fin.dgamma = dgamma;
     p.fin.dbeta = dbeta; p.fin.centered = 0;
   }
-  if (dz_early) { p.dout = dz_out; p.maskref = nullptr; p.dz_out = nullptr; }
+  if (dz_early) { p.dout = dz_out; p.maskref = nullptr; p.mask_bits = nullptr; p.dz_out = nullptr; }
   p.partial = dbias ? partial : nullptr;  // reuse (finalize already consumed it; stream-ordered)
   DISPATCH_T(dtype, (bn_bwd_launch<bf16_t, true>(p, grid, stream)), (bn_bwd_launch<float, true>(p, grid, stream)), "bn_bwd");
   ECG_CHECK_LAUNCH("bn_bwd_apply");

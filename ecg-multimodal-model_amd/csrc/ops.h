@@ -80,13 +80,17 @@ struct EcgBnFold {
 };
 bool ecg_bn_fold_ok(int C, int rows);
 int ecg_bn_act_fold(int dtype, const void* y, float* coef, const EcgBnFold& f, const void* res, const float* rcoef,
-                    const float* gate, int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream);
+                    const float* gate, int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream,
+                    unsigned char* relu_bits = nullptr);
+// relu_bits (nullable; bf16 + relu only): [M][C / 8] bytes, bit j of byte [row][k] = (out[row][8 k + j] > 0) -- the ReLU mask
+// for ecg_bn_bwd's mask_bits, 1/16 of the bytes of the activated tensor it would otherwise re-read
 int ecg_bn_act(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, const float* gate,
-               int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream);
+               int rows_per_sample, int relu, void* out, long M, int C, hipStream_t stream, unsigned char* relu_bits = nullptr);
 size_t ecg_bn_bwd_scratch(int dtype, long M, int C);
 int ecg_bn_bwd(int dtype, const void* dout, const void* maskref, const float* gate, const float* addc,
                int rows_per_sample, const void* y, const float* coef, const float* gamma, float* dgamma, float* dbeta,
-               void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream);
+               void* dy, void* dz_out, float* dbias, long M, int C, float* scratch, hipStream_t stream,
+               const unsigned char* mask_bits = nullptr);
 int ecg_bn_bwd_tail(int dtype, const void* dout, const void* maskref, const void* y, const float* coef,
                     const float* gamma, float* dgamma, float* dbeta, void* dy, const float* partial, int rows, long M,
                     int C, float* scratch, hipStream_t stream, const float* gate = nullptr, const float* addc = nullptr,

@@ -27,6 +27,12 @@ bool stem_recompute(int dtype) {
   if (g_stem_recompute < 0) { const char* e = getenv("ECGMM_STEM_RECOMPUTE"); g_stem_recompute = (e && e[0] == '1'); }
   return g_stem_recompute != 0 && ecg_stem_fused_ok(dtype, 3, 7);
 }
+// bn2's backward takes the block's ReLU mask from one bit per element written by the forward activation pass instead of re-reading
+// the activated tensor (ECGMM_RELU_BITS=0: re-read it).  Read once per process: forward and backward must agree.
+bool relu_bits_on() {
+  static const bool on = [] { const char* e = getenv("ECGMM_RELU_BITS"); return !(e && e[0] == '0'); }();
+  return on;
+}
 constexpr long FUSE_NEVER = 1L << 40;
 long g_fuse_min_m = -1;  // pixel-count threshold of the fused BatchNorm-backward reductions (-1: read ECGMM_BN_FUSE_MIN_M)
 
@@ -93,6 +99,7 @@ struct FwdWs {
   struct B {
     void *w1f, *w1d, *w2f, *w2d, *wdf, *wdd;
     void *y1, *a1, *y2, *yd, *out;
+    unsigned char* bits;   // ReLU mask of `out`, one bit per element (bf16 plans; null otherwise)
     float *coef1, *coef2, *coefd;
   } b[8];
   float* pooled;
@@ -127,6 +134,8 @@ void layout_fwd(const R18& r, void* base, FwdWs& w) {
     b.a1 = a.take_bytes(osz * es);
     b.y2 = a.take_bytes(osz * es);
     b.out = a.take_bytes(osz * es);
+    // ReLU mask of `out` as bits (bf16 training plans): bn2's backward reads these 1/16-size bytes instead of `out`
+    b.bits = es == 2 ? (unsigned char*)a.take_bytes(osz / 8) : nullptr;
     b.coef1 = a.take<float>(4 * k.cout);
     b.coef2 = a.take<float>(4 * k.cout);
     if (k.down) {
@@ -241,15 +250,15 @@ int bn_coef(const R18& r, const float* stats, int rows, int C, long count, const
 // ~5 us launch less on the forward's critical path, 16 times per forward).
 int bn_then_act(const R18& r, const float* stats, int rows, int C, long count, const void* const* params, int p_bn,
                 void* const* buffers, int b_bn, float* coef, const void* y, const void* res, const float* rcoef, void* out,
-                hipStream_t s) {
+                hipStream_t s, unsigned char* relu_bits = nullptr) {
   const int dt = r.d.dtype;
   if (r.d.training && ecg_bn_fold_ok(C, rows)) {
     EcgBnFold f = {stats, rows, (double)count, P(params, p_bn), P(params, p_bn + 1), (float*)buffers[b_bn],
                    (float*)buffers[b_bn + 1], (long long*)buffers[b_bn + 2], r.d.bn_momentum, r.d.bn_eps};
-    return ecg_bn_act_fold(dt, y, coef, f, res, rcoef, nullptr, 1, 1, out, count, C, s);
+    return ecg_bn_act_fold(dt, y, coef, f, res, rcoef, nullptr, 1, 1, out, count, C, s, relu_bits);
   }
   ECG_TRY(bn_coef(r, stats, rows, C, count, params, p_bn, buffers, b_bn, coef, s));
-  return ecg_bn_act(dt, y, coef, res, rcoef, nullptr, 1, 1, out, count, C, s);
+  return ecg_bn_act(dt, y, coef, res, rcoef, nullptr, 1, 1, out, count, C, s, relu_bits);
 }
 
 }  // namespace
@@ -400,10 +409,10 @@ extern "C" int ecgmm_resnet18_forward(const ecgmm_resnet18_desc* d, const float*
         ECG_TRY(bn_coef(r, w.stats_d, rows, k.cout, M, params, k.p_dbn, buffers, k.b_dbn, b.coefd, s));
       }
       ECG_TRY(bn_then_act(r, w.stats, e2.stats_rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, b.y2, b.yd,
-                          b.coefd, b.out, s));
+                          b.coefd, b.out, s, r.d.training && relu_bits_on() ? b.bits : nullptr));
     } else {
       ECG_TRY(bn_then_act(r, w.stats, e2.stats_rows, k.cout, M, params, k.p_bn2, buffers, k.b_bn2, b.coef2, b.y2, cur,
-                          nullptr, b.out, s));
+                          nullptr, b.out, s, r.d.training && relu_bits_on() ? b.bits : nullptr));
     }
     cur = b.out;
     ecg_tl_mark(102 + i, s);
@@ -496,7 +505,7 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
                                 G(grads, k.p_bn2 + 1), dyb, q.red2, fused2_rows, M, k.cout, q.bn_scratch, s));
       } else {
         ECG_TRY(ecg_bn_bwd(dt, dcur, b.out, nullptr, nullptr, 1, b.y2, b.coef2, P(params, k.p_bn2), G(grads, k.p_bn2),
-                           G(grads, k.p_bn2 + 1), dyb, q.dz, nullptr, M, k.cout, q.bn_scratch, s));
+                           G(grads, k.p_bn2 + 1), dyb, q.dz, nullptr, M, k.cout, q.bn_scratch, s, relu_bits_on() ? b.bits : nullptr));
       }
       if (G(grads, k.p_conv2)) {
         if (side) side_fork(s);
