@@ -446,6 +446,8 @@ extern "C" int ecgmm_resnet18_backward(const ecgmm_resnet18_desc* d, const float
   ecg_conv_wgrad_narrow(side, N >= 192 ? 192 : 256);
   struct NarrowOff { ~NarrowOff() { ecg_conv_wgrad_narrow(false); } } narrow_off;
   hipStream_t ws = side ? g_side.s : s;  // stream of the weight-gradient kernels
+  // (capping the persistent input-gradient kernels of this call to the CUs the side stream leaves free -- 160 / 192 / 224 of 256 --
+  //  measured 6.57-6.60 / 6.62-6.63 / 6.53-6.55 ms against 6.54-6.56 uncapped: the weight gradients hold their CUs only part of the time)
 
   if (stage_begin == 0) ecg_tl_mark(200, s);
   for (int st = stage_begin; st < stage_end; ++st) {
