@@ -337,6 +337,22 @@ __global__ __launch_bounds__(BN_ACT_THREADS) void bn_act_kernel(BnActParams p) {
   __shared__ float s_coef[2 * 512];
   const float* cf = p.coef;
   int cfs = p.C;           // stride between the scale and the shift rows
+  // (fold form: the first trip's loads are issued BEFORE the fold of the partial rows, whose ~3 us then hide their HBM latency)
+  const T* y = (const T*)p.y;
+  const T* res = (const T*)p.res;
+  const long stride = (long)gridDim.x * rpi;
+  const long rfirst = (long)blockIdx.x * rpi + r0;
+  u32x4 py[2] = {}, pr[2] = {};
+  bool pre = p.fin.partial != nullptr && rfirst < p.M;
+  if (pre) {
+    const long q2 = rfirst + stride < p.M ? rfirst + stride : rfirst;
+    py[0] = ld16s(y + rfirst * p.C + c0);
+    py[1] = ld16s(y + q2 * p.C + c0);
+    if (res) {
+      pr[0] = ld16s(res + rfirst * p.C + c0);
+      pr[1] = ld16s(res + q2 * p.C + c0);
+    }
+  }
   if (p.fin.partial) {
     bn_fin_prologue<BN_ACT_THREADS>(p.fin, p.C, s_coef, s_red);
     cf = s_coef;
@@ -349,21 +365,23 @@ __global__ __launch_bounds__(BN_ACT_THREADS) void bn_act_kernel(BnActParams p) {
     rs[j] = p.rcoef ? p.rcoef[c0 + j] : 1.f;
     rb[j] = p.rcoef ? p.rcoef[p.C + c0 + j] : 0.f;
   }
-  const T* y = (const T*)p.y;
-  const T* res = (const T*)p.res;
   T* out = (T*)p.out;
   // two rows per iteration, all (up to four) 16-B loads issued before the first use
-  const long stride = (long)gridDim.x * rpi;
-  for (long r = (long)blockIdx.x * rpi + r0; r < p.M; r += 2 * stride) {
+  for (long r = rfirst; r < p.M; r += 2 * stride) {
     const long r2 = r + stride;
     const bool two = r2 < p.M;
     const long rb2 = two ? r2 : r;
     u32x4 vy[2], vr[2];
-    vy[0] = ld16s(y + r * p.C + c0);
-    vy[1] = ld16s(y + rb2 * p.C + c0);
-    if (res) {
-      vr[0] = ld16s(res + r * p.C + c0);
-      vr[1] = ld16s(res + rb2 * p.C + c0);
+    if (pre) {
+      vy[0] = py[0]; vy[1] = py[1]; vr[0] = pr[0]; vr[1] = pr[1];
+      pre = false;
+    } else {
+      vy[0] = ld16s(y + r * p.C + c0);
+      vy[1] = ld16s(y + rb2 * p.C + c0);
+      if (res) {
+        vr[0] = ld16s(res + r * p.C + c0);
+        vr[1] = ld16s(res + rb2 * p.C + c0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -439,6 +457,14 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
   __shared__ double s_red[APPLY ? FIN_LDS_DOUBLES : 1];
   __shared__ float s_bcoef[APPLY ? 3 * 512 : 1];
   const float* bc = p.bcoef;
+  // (fold form: the first row's loads are issued before the fold, as in bn_act_kernel)
+  const long rfirst = (long)blockIdx.x * rpi + r0;
+  u32x4 pd = {}, pv = {};
+  bool pre = APPLY && p.fin.partial != nullptr && rfirst < p.M;
+  if (pre) {
+    pd = ld16s((const T*)p.dout + rfirst * p.C + c0);
+    pv = ld16s((const T*)p.y + rfirst * p.C + c0);
+  }
   if (APPLY && p.fin.partial) {
     bn_bwd_fin_prologue<BWD_THREADS>(p.fin, p.coef, p.C, s_bcoef, s_red);
     bc = s_bcoef;
@@ -460,10 +486,16 @@ __global__ __launch_bounds__(BWD_THREADS) void bn_bwd_kernel(BnBwdParams p) {
   const T* dout = (const T*)p.dout;
   const T* mref = (const T*)p.maskref;
   const T* y = (const T*)p.y;
-  for (long r = (long)blockIdx.x * rpi + r0; r < p.M; r += (long)gridDim.x * rpi) {
+  for (long r = rfirst; r < p.M; r += (long)gridDim.x * rpi) {
     float d[VEC], m[VEC], v[VEC];
-    unpack16<T>(ld16s(dout + r * p.C + c0), d);
-    unpack16<T>(ld16s(y + r * p.C + c0), v);
+    if (pre) {
+      unpack16<T>(pd, d);
+      unpack16<T>(pv, v);
+      pre = false;
+    } else {
+      unpack16<T>(ld16s(dout + r * p.C + c0), d);
+      unpack16<T>(ld16s(y + r * p.C + c0), v);
+    }
     if (mref == y) {
       // maskref aliasing y: the ReLU input was bn(y) itself, so the mask is recomputed through the
       // BatchNorm affine instead of reading the activated tensor (one tensor read less)
@@ -1327,16 +1359,19 @@ int ecg_col_stats(int dtype, const void* x, long M, int C, float* partial, int* 
   return 0;
 }
 
-// Finalize folded into the consumer (kernels above): ECGMM_BN_FOLD=0 / ecgmm_bn_fold(0) restores the separate launches.
+// Finalize folded into the consumer (kernels above; default): ECGMM_BN_FOLD=0 / ecgmm_bn_fold(0) restores the separate launches.
 static int g_bn_fold = -1;
 extern "C" int ecgmm_bn_fold(int on) {
   g_bn_fold = on != 0;
   return 0;
 }
 bool ecg_bn_fold_ok(int C, int rows) {
-  // DEFAULT OFF: same-call A/B at batch 256 (round 3): 6.98 ms with the separate launches, 7.04 ms folded -- 256 workgroups
-  // each re-reading the same 128-256 KB of partial rows cost the L2 what the ~5 us launch + its boundary cost the stream.
-  if (g_bn_fold < 0) { const char* e = getenv("ECGMM_BN_FOLD"); g_bn_fold = (e && e[0] == '1'); }
+  // Mid-round 3 this measured 6.98 ms with the separate launches against 7.04 ms folded (256 workgroups each re-reading the same
+  // 128-256 KB of partial rows cost what the ~5 us launch + its boundary cost the stream).  With the consumers' first loads issued
+  // BEFORE the fold -- its ~3 us then cover their HBM latency -- the folded form is the faster one: same-call A/B 6.47, 6.46 ->
+  // 6.44, 6.46 ms (multimodal batch 256), 2.96, 2.97 -> 2.95, 2.97 (12-lead batch 512), 3.44, 3.45 -> 3.44, 3.44 (image-only batch
+  // 128), and 35 launches fewer per step.  DEFAULT ON; ECGMM_BN_FOLD=0 / ecgmm_bn_fold(0) restores the separate launches.
+  if (g_bn_fold < 0) { const char* e = getenv("ECGMM_BN_FOLD"); g_bn_fold = !(e && e[0] == '0'); }
   if (!g_bn_fold || rows < 1 || rows > 512 || C > 512) return false;
   return C >= 128 ? C % 128 == 0 : (C >= 16 && 1024 % C == 0);
 }
