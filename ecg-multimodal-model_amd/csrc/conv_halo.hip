@@ -617,12 +617,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     // all of steps t - 1 and t.  A store has three and a half steps (~1.2 us) for its write acknowledgement; a halo piece
     // (HBM) has landed by the wait of step 8 at the latest (pieces are issued in steps 0-5), in front of whose barrier nobody
     // reads the next tile's halo.
-    // AD (input gradient + residual addend): a quarter's 16-byte addend load is issued TWO steps ahead of the quarter
-    // (loads in steps 1-4 into two alternating register sets, quarters in steps 3-6: hipcc waits for them itself, with a count
+    // AD (input gradient + residual addend): a quarter's 16-byte addend load is issued THREE steps ahead of the quarter
+    // (loads in steps 1-4 into three rotating register sets, quarters in steps 4-7: hipcc waits for them itself, with a count
     // that is exact in this straight-line body), and their lines were pulled into L2 by one 4-byte LDS-DMA per wave in step 5 of
     // the tile that computed them (a wave's 64 pixels x its 64 bytes: one lane per line) -- a load waited for one step after its
     // issue, or served from HBM, would stall the whole in-order vmcnt queue.
-    constexpr auto st_ = [](int t) { t = (t + RS) % RS; return AD ? (t >= 3 && t <= 6 ? 1 : 0) : (t >= 1 && t <= 4 ? 1 : 0); };
+    constexpr auto st_ = [](int t) { t = (t + RS) % RS; return AD ? (t >= 4 && t <= 7 ? 1 : 0) : (t >= 1 && t <= 4 ? 1 : 0); };
     constexpr auto ld_ = [](int t) { t = (t + RS) % RS; return AD && t >= 1 && t <= 4 ? 1 : 0; };
     constexpr auto pf_ = [](int t) { t = (t + RS) % RS; return AD && t == 5 ? 1 : 0; };
     constexpr auto ex_ = [=](int t) { return st_(t) + ld_(t) + pf_(t); };   // vector-memory operations of a step's VALU part
@@ -638,9 +638,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
     // (ONE 16-byte load per lane in the STORE layout -- the 8 consecutive channels of the pixel this lane stores -- instead of an
     //  8-byte load per channel tile in the accumulator layout: whole 64-byte runs per pixel; the row swap that builds the store
     //  layout is its own inverse, so two v_permlane16_swap take the addend back to the accumulators' lanes)
-    u32x4 adv[2];
+    u32x4 adv[3];
     auto load_addend = [&](int b, int m0_) {
-      adv[b & 1] = *reinterpret_cast<const u32x4*>(addend + (size_t)(m0_ + wp * 64 + b * 16 + fr) * p.Cd + cw + cl);
+      adv[b % 3] = *reinterpret_cast<const u32x4*>(addend + (size_t)(m0_ + wp * 64 + b * 16 + fr) * p.Cd + cw + cl);
     };
     auto prefetch_addend = [&](int m0_) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #if defined(__HIP_DEVICE_COMPILE__)
       f32x4 v0 = accp[0][b], v1 = accp[1][b];
       if constexpr (AD) {
-        const u32x4 ao = adv[b & 1];
+        const u32x4 ao = adv[b % 3];
         auto ax = __builtin_amdgcn_permlane16_swap(ao[0], ao[2], false, false);   // channels 0-1 of tile 0 | of tile 1
         auto ay = __builtin_amdgcn_permlane16_swap(ao[1], ao[3], false, false);   // channels 2-3
         v0 += (f32x4){__uint_as_float(ax[0] << 16), __uint_as_float(ax[0] & 0xFFFF0000u), __uint_as_float(ay[0] << 16), __uint_as_float(ay[0] & 0xFFFF0000u)};
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_halo_kernel(Hal
 #if defined(HALO_ABL) && HALO_ABL == 10   // diagnostic 10 (timing only): the stream form without its in-loop epilogue pieces (same vm-op counts)
             dummy_vm();
 #else
-            epi_unit(AD ? t - 3 : t - 1, m0_prev);
+            epi_unit(AD ? t - 4 : t - 1, m0_prev);
 #endif
           }
           if (ld_(t)) load_addend(t - 1, m0_prev);   // (behind the quarter that used this register set)
